@@ -1,0 +1,163 @@
+/* rbp.h — C ABI of the MI355X-native RBP plan path (SFC + RSFC + QP).
+ *
+ * This is the drop-in boundary for the two header-only C++ stages of the reference
+ *   SwarmPlanning::Corridor::update(bool, PlanResult*)    swarm_planner/include/rbp_corridor.hpp:21-26
+ *   SwarmPlanning::RBPPlanner::update(bool, PlanResult*)  swarm_planner/include/rbp_planner.hpp:33-84
+ * The reference has no FFI; the shared state between the stages is `PlanResult`
+ * (swarm_planner/include/sp_const.hpp:21-28).  Here the same state is a set of caller-owned flat
+ * arrays (`rbp_plan`), the distance map is a flat float grid (`rbp_world`, what
+ * DynamicEDTOctomap::getDistance serves in rbp_corridor.hpp:66) and Mission/Param are plain structs
+ * (mission.hpp:13-15, param.hpp:44-70).  INTEGRATION.md shows the ~80-line adapter a maintainer of
+ * the reference would add.
+ *
+ * All pointers are HOST pointers unless a function says otherwise.  Plain C, no torch types.
+ */
+#ifndef RBP_H
+#define RBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (the reference returns bool + ROS_ERROR; 0 == true) ------------------------- */
+enum {
+    RBP_OK = 0,
+    RBP_ERR_OBSTACLE_IN_INIT_TRAJ = 1, /* rbp_corridor.hpp:181-187 "Obstacle invades initial trajectory" */
+    RBP_ERR_UNEQUAL_TRAJ_LEN = 2,      /* rbp_corridor.hpp:346-349 (cannot happen with the flat layout; kept) */
+    RBP_ERR_INIT_TRAJ_COLLIDE = 3,     /* rbp_corridor.hpp:385-388 "initial trajectories are collided" */
+    RBP_ERR_SFC_OVERFLOW = 4,          /* more boxes than plan->max_boxes (flat-layout only) */
+    RBP_ERR_QP_FAILED = 10,            /* rbp_planner.hpp:158-161 "Failed to optimize QP" (infeasible / no convergence) */
+    RBP_ERR_UNSUPPORTED_DEGREE = 11,   /* rbp_planner.hpp:344-346, 375-377: only n=5, phi=3 */
+    RBP_ERR_BAD_ARGUMENT = 20,
+    RBP_ERR_NO_DEVICE = 30,            /* HIP device / kernel image unavailable: the product path never falls back to CPU */
+    RBP_ERR_HIP = 31
+};
+
+/* ---- distance map: what DynamicEDTOctomap(maxDist=1, tree, bbxMin, bbxMax, false) serves -------
+ * swarm_planner/src/swarm_traj_planner_rbp.cpp:73-80.  Cell (ix,iy,iz) holds the voxel whose octomap key
+ * (minus 32768) is key_min + (ix,iy,iz); a point p maps to key floor((1/res) * (double)p) per axis and
+ * reads -1 outside the grid (so out-of-world samples count as obstacle in rbp_corridor.hpp:67). */
+typedef struct rbp_world {
+    int32_t dim[3];     /* nx, ny, nz */
+    int32_t key_min[3]; /* voxel key of cell (0,0,0), relative to the octree centre */
+    double res;         /* octree resolution [m] */
+    const float* dist;  /* [nx][ny][nz], metres, z fastest */
+} rbp_world;
+
+/* ---- mission.hpp:13-15 ---------------------------------------------------------------------- */
+typedef struct rbp_mission {
+    int32_t N;             /* qn */
+    const double* start;   /* [N][9]  pos(3) vel(3) acc(3)   mission.hpp:47-53 */
+    const double* goal;    /* [N][9]                         mission.hpp:55-61 */
+    const double* radius;  /* [N]     quad_size              mission.hpp:64 */
+    const double* max_vel; /* [N][3]                         mission.hpp:70-76 */
+    const double* max_acc; /* [N][3]                         mission.hpp:78-83 */
+} rbp_mission;
+
+/* ---- param.hpp:44-70 (names and defaults are the reference's) -------------------------------- */
+typedef struct rbp_param {
+    double world_min[3]; /* world/x_min,y_min,z_min  (-5,-5,0)   */
+    double world_max[3]; /* world/x_max,y_max,z_max  (5,5,2.5)   */
+    double box_xy_res;   /* box/xy_res 0.1 */
+    double box_z_res;    /* box/z_res  0.1 */
+    double downwash;     /* plan/downwash 2.0 */
+    double time_step;    /* plan/time_step 1 */
+    double ecbs_w;       /* ecbs/w 1.3        (front-end only) */
+    double grid_xy_res;  /* grid/xy_res 0.3   (front-end only) */
+    double grid_z_res;   /* grid/z_res 0.6    (front-end only) */
+    double grid_margin;  /* grid/margin 0.2   (front-end only) */
+    int32_t n;           /* plan/n 5   */
+    int32_t phi;         /* plan/phi 3 */
+    int32_t sequential;  /* plan/sequential false */
+    int32_t batch_size;  /* plan/batch_size 4 */
+    int32_t batch_iter;  /* plan/batch_iter 0 (launch files pass -1 = all batches) */
+    int32_t iteration;   /* plan/iteration 1 */
+    int32_t time_scale;  /* plan/time_scale true */
+    int32_t log;         /* log false */
+} rbp_param;
+
+/* Fill `p` with the defaults of Param::setROSParam (param.hpp:44-70). */
+void rbp_param_defaults(rbp_param* p);
+
+/* ---- PlanResult (sp_const.hpp:21-28) as flat caller-owned arrays ------------------------------
+ * pair index of (qi<qj):  qi*N - qi*(qi+1)/2 + (qj-qi-1)   (the order RSFC[qi][qj] is filled in
+ * rbp_corridor.hpp:342-344). */
+typedef struct rbp_plan {
+    int32_t N;              /* agents (== mission.N) */
+    int32_t M;              /* segments = T.size()-1            rbp_planner.hpp:35 */
+    double* T;              /* [M+1] segment times; rescaled in place by time_scale (rbp_planner.hpp:262-264) */
+    const float* init_traj; /* [N][M+1][3] float32 = octomap::point3d waypoints (sp_const.hpp:16) */
+
+    /* SFC_t (sp_const.hpp:17): per agent a list of (box[6] = xmin,ymin,zmin,xmax,ymax,zmax ; end time) */
+    int32_t max_boxes;      /* capacity per agent; M always suffices */
+    int32_t* sfc_count;     /* [N] */
+    double* sfc_box;        /* [N][max_boxes][6] */
+    double* sfc_time;       /* [N][max_boxes]     rescaled by time_scale (rbp_planner.hpp:250-252) */
+
+    /* RSFC_t (sp_const.hpp:18): per pair and segment (float32 normal ; time T[m+1]) */
+    float* rsfc_normal;     /* [N(N-1)/2][M][3] */
+    double* rsfc_time;      /* [M]  (= T[1..M], identical for every pair; rescaled like rbp_planner.hpp:255-258) */
+
+    /* RBPPlanner outputs */
+    double* coef;           /* [N][3][6M]: per agent the column-major (6M x 3) matrix the reference copies into
+                               msgs_traj_coef[qi].data (rbp_planner.hpp:286-289); rows m*6+i hold the coefficient of
+                               (t-T_m)^(5-i), i.e. descending powers, seconds (rbp_planner.hpp:170-186) */
+    double* ctrl;           /* [N][3][6M] Bernstein control points (the reference's `dummy`/`vals`), may be NULL */
+    double time_scale;      /* rbp_planner.hpp:235 */
+    double total_cost;      /* "QP total cost" rbp_planner.hpp:205: sum of batch objectives of the last pass */
+    int32_t x_size;         /* count_x  of the last batch  rbp_planner.hpp:58 */
+    int32_t eq_size;        /* count_eq                    rbp_planner.hpp:59 */
+    int32_t ineq_size;      /* count_lq                    rbp_planner.hpp:60 */
+    int32_t qp_iterations;  /* total interior-point iterations spent (diagnostic, not in the reference) */
+} rbp_plan;
+
+/* ---- the two stage calls (synchronous; results on return) -------------------------------------
+ * Corridor::update: reads world, mission.radius, param.{world_*,box_*,downwash}, plan.{T,init_traj};
+ * writes plan.{sfc_*, rsfc_*}.  Unlike the reference (which appends, rbp_corridor.hpp:153,190) the
+ * outputs are overwritten. */
+int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
+
+/* RBPPlanner::update: reads mission, param, plan.{T,init_traj,sfc_*,rsfc_*}; writes plan.{coef,ctrl,
+ * time_scale,total_cost,*_size} and rescales T / sfc_time / rsfc_time when time_scale != 1. */
+int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
+
+/* ---- device-resident, batched form (what bench.py times) --------------------------------------
+ * A session owns the HBM copies of K independent missions (e.g. the 50-map sweep of
+ * swarm_traj_planner_rbp_test_all.cpp:49-103).  `run` only enqueues kernels on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream) and never synchronises. */
+typedef struct rbp_session rbp_session;
+
+enum { RBP_STAGE_CORRIDOR = 1, RBP_STAGE_PLANNER = 2, RBP_STAGE_ALL = 3 };
+
+/* worlds/missions/plans: arrays of K structs (host side); all plans must share N and M. */
+int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
+                       const rbp_param* param, const rbp_plan* plans);
+int rbp_session_run(rbp_session* s, int stages, void* stream);
+/* blocks on `stream`, copies outputs into plans[0..K-1]; returns the first non-zero per-mission status
+ * and, if `status` != NULL, every mission's status in status[0..K-1]. */
+int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream);
+/* restore T / corridor state to what was uploaded, so that `run` can be repeated (bench loops) */
+int rbp_session_reset(rbp_session* s, void* stream);
+void rbp_session_destroy(rbp_session* s);
+
+/* work counters of the last `run`, for the roofline report: see DESIGN.md */
+typedef struct rbp_counters {
+    double sfc_samples;     /* getDistance-equivalent samples tested by the SFC kernel (summed over missions) */
+    double qp_flops;        /* flops of the dense block factorisations/solves the QP kernel executed */
+    double qp_ipm_iters;    /* interior-point iterations summed over QPs */
+    double qp_solves;       /* number of batch QPs solved */
+    double qp_constraint_rows; /* inequality rows swept (rows x passes) */
+} rbp_counters;
+int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
+
+/* library/version/diagnostics */
+const char* rbp_version(void);
+const char* rbp_last_error(void);
+int rbp_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBP_H */

@@ -1,0 +1,143 @@
+"""Host front-end (not accelerated): mission JSON, octomap .bt -> distance grid, ECBS initial trajectories.
+
+Thin ctypes binding of lib/librbp_host.so (include/rbp_host.h).  These are the callers/data formats either
+side of the hot path (reference: mission.hpp:22-88, swarm_traj_planner_rbp_test_all.cpp:51-63,
+ecbs_planner.hpp:21-136).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+from .types import Mission, Param, PlanResult, World
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(A.LIB_DIR, "librbp_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C swarm_simulator_amd/csrc host`")
+        L = C.CDLL(path)
+        L.rbp_mission_load_json.argtypes = [C.c_char_p, C.POINTER(A.rbp_mission_buf)]
+        L.rbp_mission_free.argtypes = [C.POINTER(A.rbp_mission_buf)]
+        L.rbp_mission_free.restype = None
+        L.rbp_octomap_load_bt.argtypes = [C.c_char_p, C.POINTER(A.rbp_octomap_buf)]
+        L.rbp_octomap_free.argtypes = [C.POINTER(A.rbp_octomap_buf)]
+        L.rbp_octomap_free.restype = None
+        L.rbp_world_build.argtypes = [C.POINTER(A.rbp_octomap_buf), C.c_double * 3, C.c_double * 3, C.c_double,
+                                      C.POINTER(A.rbp_world_buf)]
+        L.rbp_world_free.argtypes = [C.POINTER(A.rbp_world_buf)]
+        L.rbp_world_free.restype = None
+        L.rbp_ecbs_plan.argtypes = [C.POINTER(A.rbp_world_buf), C.POINTER(A.rbp_mission), C.POINTER(A.rbp_param),
+                                    C.c_int64, C.POINTER(A.rbp_init_traj_buf)]
+        L.rbp_init_traj_free.argtypes = [C.POINTER(A.rbp_init_traj_buf)]
+        L.rbp_init_traj_free.restype = None
+        L.rbp_validate.argtypes = [C.POINTER(A.rbp_mission), C.POINTER(A.rbp_param), C.c_int32, A.c_double_p,
+                                   A.c_double_p, C.c_double, A.c_double_p, A.c_double_p]
+        L.rbp_write_coef_csv.argtypes = [C.c_char_p, C.c_int32, C.c_int32, A.c_double_p, A.c_double_p]
+        _lib = L
+    return _lib
+
+
+def _np(p, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    return np.ctypeslib.as_array(p, shape=(n,)).astype(dtype, copy=True).reshape(shape)
+
+
+def data_path(*parts):
+    """committed input fixtures: data/missions/*.json, data/worlds/*.bt (the reference's own files)."""
+    return os.path.join(A.REPO_ROOT, "data", *parts)
+
+
+def load_mission(path) -> Mission:
+    """Mission::setMission (mission.hpp:22-88)."""
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = data_path("missions", path)
+    buf = A.rbp_mission_buf()
+    rc = lib().rbp_mission_load_json(path.encode(), C.byref(buf))
+    if rc:
+        raise ValueError(f"There is no such mission file {path} (rc={rc})")
+    N = buf.N
+    m = Mission(_np(buf.start, (N, 9), np.float64), _np(buf.goal, (N, 9), np.float64), _np(buf.radius, (N,), np.float64),
+                _np(buf.max_vel, (N, 3), np.float64), _np(buf.max_acc, (N, 3), np.float64),
+                _np(buf.speed, (N,), np.float64))
+    lib().rbp_mission_free(C.byref(buf))
+    return m
+
+
+def load_octomap(path):
+    """occupied leaves of an octomap binary tree: (keys[n][4] = x,y,z,size ; res ; node count)."""
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = data_path("worlds", path)
+    buf = A.rbp_octomap_buf()
+    rc = lib().rbp_octomap_load_bt(path.encode(), C.byref(buf))
+    if rc:
+        raise ValueError(f"cannot read octomap {path} (rc={rc})")
+    keys = _np(buf.keys, (buf.n_occupied, 4), np.int32)
+    res, nodes = buf.res, buf.n_nodes
+    lib().rbp_octomap_free(C.byref(buf))
+    return keys, res, nodes
+
+
+def build_world(keys, res, param: Param, max_dist=1.0) -> World:
+    """DynamicEDTOctomap(maxDist, tree, world_min, world_max, false).update()
+    (swarm_traj_planner_rbp_test_all.cpp:57-63)."""
+    ob = A.rbp_octomap_buf()
+    keys = np.ascontiguousarray(keys, np.int32)
+    ob.res, ob.n_occupied, ob.keys, ob.n_nodes = res, len(keys), A.ptr(keys, A.c_int32_p), 0
+    wb = A.rbp_world_buf()
+    lo = (C.c_double * 3)(param.world_x_min, param.world_y_min, param.world_z_min)
+    hi = (C.c_double * 3)(param.world_x_max, param.world_y_max, param.world_z_max)
+    rc = lib().rbp_world_build(C.byref(ob), lo, hi, max_dist, C.byref(wb))
+    if rc:
+        raise ValueError(f"rbp_world_build failed rc={rc}")
+    shape = tuple(wb.dim)
+    w = World(_np(wb.dist, shape, np.float32), tuple(wb.key_min), wb.res)
+    lib().rbp_world_free(C.byref(wb))
+    return w
+
+
+def load_world(path, param: Param) -> World:
+    keys, res, _ = load_octomap(path)
+    return build_world(keys, res, param)
+
+
+def ecbs_plan(world: World, mission: Mission, param: Param, max_nodes=200000) -> PlanResult:
+    """ECBSPlanner::update (ecbs_planner.hpp:21-72): returns a PlanResult holding initTraj and T."""
+    out = A.rbp_init_traj_buf()
+    wb, ms, ps = world.c_buf(), mission.c_struct(), param.c_struct()
+    rc = lib().rbp_ecbs_plan(C.byref(wb), C.byref(ms), C.byref(ps), max_nodes, C.byref(out))
+    if rc:
+        raise RuntimeError({1: "ECBSPlanner: start/goal occluded by obstacle", 2: "ECBSPlanner: ECBS Failed!"}.get(rc, f"rc={rc}"))
+    N, M = out.N, out.M
+    pr = PlanResult(_np(out.init_traj, (N, M + 1, 3), np.float32), _np(out.T, (M + 1,), np.float64))
+    pr.ecbs_stats = dict(makespan=out.makespan, sum_cost=out.sum_cost, high_level=out.high_level_expanded,
+                         low_level=out.low_level_expanded)
+    lib().rbp_init_traj_free(C.byref(out))
+    return pr
+
+
+def validate(mission: Mission, param: Param, plan: PlanResult, dt=0.1):
+    """(min safety-margin ratio, total flight distance) — rbp_publisher.hpp:769-798, 685-695."""
+    ms, ps = mission.c_struct(), param.c_struct()
+    ratio, dist = C.c_double(), C.c_double()
+    rc = lib().rbp_validate(C.byref(ms), C.byref(ps), plan.M, A.ptr(plan.T, A.c_double_p), A.ptr(plan.coef, A.c_double_p),
+                            dt, C.byref(ratio), C.byref(dist))
+    if rc:
+        raise RuntimeError(f"rbp_validate rc={rc}")
+    return ratio.value, dist.value
+
+
+def write_coef_csv(directory, plan: PlanResult):
+    """generateCoefCSV (rbp_planner.hpp:295-324)."""
+    os.makedirs(directory, exist_ok=True)
+    rc = lib().rbp_write_coef_csv(directory.encode(), plan.N, plan.M, A.ptr(plan.T, A.c_double_p), A.ptr(plan.coef, A.c_double_p))
+    if rc:
+        raise RuntimeError(f"rbp_write_coef_csv rc={rc}")

@@ -1,0 +1,143 @@
+"""ctypes binding of the CPU oracle (oracle/_build/librbp_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd.types import Mission, Param, PlanResult, World
+
+ORACLE_DIR = os.path.join(A.REPO_ROOT, "oracle")
+_lib = None
+
+
+class oracle_qp_options(C.Structure):
+    _fields_ = [("linear_solver", C.c_int32), ("max_iter", C.c_int32), ("tol_feas", C.c_double),
+                ("tol_gap", C.c_double), ("verbose", C.c_int32), ("polish", C.c_int32)]
+
+
+class oracle_qp_report(C.Structure):
+    _fields_ = [("n_qp", C.c_int32), ("iters_total", C.c_int32), ("iters_max", C.c_int32), ("n_polished", C.c_int32),
+                ("kkt_stationarity", C.c_double), ("kkt_primal_eq", C.c_double), ("kkt_primal_ineq", C.c_double),
+                ("kkt_dual_min", C.c_double), ("kkt_compl", C.c_double), ("duality_gap_rel", C.c_double),
+                ("flops", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "_build", "librbp_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        P = C.POINTER
+        L.oracle_corridor_update.argtypes = [P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan), P(C.c_int64)]
+        L.oracle_planner_update.argtypes = [P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan), P(oracle_qp_options),
+                                            P(oracle_qp_report)]
+        L.oracle_is_obstacle_in_box.argtypes = [P(A.rbp_world), P(A.rbp_param), C.c_double * 6, C.c_double]
+        L.oracle_expand_box.argtypes = [P(A.rbp_world), P(A.rbp_param), C.c_double * 6, C.c_double]
+        L.oracle_expand_box.restype = None
+        L.oracle_rsfc_normal.argtypes = [A.c_float_p] * 4 + [C.c_double, A.c_float_p]
+        L.oracle_qp_default_options.argtypes = [P(oracle_qp_options)]
+        L.oracle_qp_default_options.restype = None
+        L.oracle_build_Q_base.argtypes = [A.c_double_p, A.c_double_p]
+        L.oracle_build_Q_base.restype = None
+        L.oracle_build_Aeq_base.argtypes = [C.c_int, A.c_double_p, A.c_double_p]
+        L.oracle_build_Aeq_base.restype = None
+        L.oracle_build_dummy.argtypes = [C.c_int, C.c_int, A.c_float_p, A.c_double_p]
+        L.oracle_build_dummy.restype = None
+        L.oracle_evaluate_ctrl.argtypes = [P(A.rbp_mission), P(A.rbp_plan), A.c_double_p] + [A.c_double_p] * 4
+        L.oracle_ctrl_to_coef.argtypes = [C.c_int, C.c_int, A.c_double_p, A.c_double_p, A.c_double_p]
+        L.oracle_ctrl_to_coef.restype = None
+        L.oracle_time_scale.argtypes = [P(A.rbp_mission), P(A.rbp_plan)]
+        L.oracle_time_scale.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def corridor_update(world: World, mission: Mission, param: Param, plan: PlanResult):
+    """returns (rc, n_getDistance_samples)"""
+    w, m, p, pl = world.c_struct(), mission.c_struct(), param.c_struct(), plan.c_struct()
+    ns = C.c_int64(0)
+    rc = lib().oracle_corridor_update(C.byref(w), C.byref(m), C.byref(p), C.byref(pl), C.byref(ns))
+    return rc, ns.value
+
+
+def planner_update(mission: Mission, param: Param, plan: PlanResult, linear_solver=0, verbose=0, tol_feas=None,
+                   tol_gap=None, max_iter=None, polish=None):
+    """returns (rc, report dict)"""
+    m, p, pl = mission.c_struct(), param.c_struct(), plan.c_struct()
+    opt = oracle_qp_options()
+    lib().oracle_qp_default_options(C.byref(opt))
+    opt.linear_solver, opt.verbose = linear_solver, verbose
+    if tol_feas is not None:
+        opt.tol_feas = tol_feas
+    if tol_gap is not None:
+        opt.tol_gap = tol_gap
+    if max_iter is not None:
+        opt.max_iter = max_iter
+    if polish is not None:
+        opt.polish = int(polish)
+    rep = oracle_qp_report()
+    rc = lib().oracle_planner_update(C.byref(m), C.byref(p), C.byref(pl), C.byref(opt), C.byref(rep))
+    plan.sync_from(pl)
+    return rc, rep.as_dict()
+
+
+def evaluate_ctrl(mission: Mission, plan: PlanResult, ctrl=None):
+    """(objective, viol_eq, viol_box, viol_rsfc) of control points under the reference's constraint sets."""
+    m, pl = mission.c_struct(), plan.c_struct()
+    ctrl = plan.ctrl if ctrl is None else A.as_f64(ctrl)
+    out = [C.c_double() for _ in range(4)]
+    lib().oracle_evaluate_ctrl(C.byref(m), C.byref(pl), A.ptr(ctrl, A.c_double_p), *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def Q_base():
+    Q, B = np.zeros((6, 6)), np.zeros((6, 6))
+    lib().oracle_build_Q_base(A.ptr(Q, A.c_double_p), A.ptr(B, A.c_double_p))
+    return Q, B
+
+
+def Aeq_base(T):
+    T = A.as_f64(T)
+    M = len(T) - 1
+    Aeq = np.zeros((3 * (M + 1), 6 * M))
+    lib().oracle_build_Aeq_base(M, A.ptr(T, A.c_double_p), A.ptr(Aeq, A.c_double_p))
+    return Aeq
+
+
+def build_dummy(init_traj):
+    tr = A.as_f32(init_traj)
+    N, P, _ = tr.shape
+    d = np.zeros((N, 3, 6 * (P - 1)))
+    lib().oracle_build_dummy(N, P - 1, A.ptr(tr, A.c_float_p), A.ptr(d, A.c_double_p))
+    return d
+
+
+def rsfc_normal(pi0, pi1, pj0, pj1, downwash):
+    arrs = [A.as_f32(a) for a in (pi0, pi1, pj0, pj1)]
+    out = np.zeros(3, np.float32)
+    rc = lib().oracle_rsfc_normal(*[A.ptr(a, A.c_float_p) for a in arrs], downwash, A.ptr(out, A.c_float_p))
+    return rc, out
+
+
+def ctrl_to_coef(T, ctrl):
+    ctrl = A.as_f64(ctrl)
+    T = A.as_f64(T)
+    N = ctrl.shape[0]
+    coef = np.zeros_like(ctrl)
+    lib().oracle_ctrl_to_coef(N, len(T) - 1, A.ptr(T, A.c_double_p), A.ptr(ctrl, A.c_double_p), A.ptr(coef, A.c_double_p))
+    return coef
