@@ -1,0 +1,353 @@
+// session.hip — the C ABI of include/rbp.h on top of the HIP kernels.
+//
+// rbp_corridor_update / rbp_planner_update are the drop-in calls for Corridor::update (rbp_corridor.hpp:21-26)
+// and RBPPlanner::update (rbp_planner.hpp:33-84); they are thin wrappers over the device-resident, batched
+// session API that bench.py times.  There is NO CPU fallback: without a HIP device every call fails with
+// RBP_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../kernels/rbp_dev.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? RBP_ERR_NO_DEVICE : RBP_ERR_HIP, \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+    } while (0)
+
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, off = 0;
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct rbp_session {
+    int device = 0;
+    DevSession d{};
+    rbp_param param{};
+    Arena arena;
+    void* qp_ws = nullptr;
+    size_t qp_ws_per_mission = 0;
+    std::vector<double> T0;           // uploaded T, for reset
+    std::vector<DevWorld> worlds_h;
+    // planner-stage inputs as uploaded (so that a planner-only run can be reset, too)
+    std::vector<int> sfc_count0;
+    std::vector<double> sfc_box0, sfc_time0, rsfc_time0;
+    std::vector<float> rsfc_normal0;
+    bool have_corridor_inputs = false;
+};
+
+extern "C" {
+
+const char* rbp_version(void) { return "rbp-mi355x 0.1 (gfx950)"; }
+const char* rbp_last_error(void) { return g_err.c_str(); }
+
+int rbp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rbp_param_defaults(rbp_param* p) {  // param.hpp:44-70
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->world_min[0] = -5, p->world_min[1] = -5, p->world_min[2] = 0;
+    p->world_max[0] = 5, p->world_max[1] = 5, p->world_max[2] = 2.5;
+    p->grid_xy_res = 0.3, p->grid_z_res = 0.6, p->grid_margin = 0.2, p->ecbs_w = 1.3;
+    p->box_xy_res = 0.1, p->box_z_res = 0.1;
+    p->time_scale = 1, p->time_step = 1, p->downwash = 2.0;
+    p->n = 5, p->phi = 3, p->sequential = 0, p->batch_size = 4, p->batch_iter = 0, p->iteration = 1;
+    p->log = 0;
+}
+
+static size_t al(size_t n) { return ((n + 255) & ~size_t(255)) + 256; }
+
+int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
+                       const rbp_param* param, const rbp_plan* plans) {
+    if (!out || K <= 0 || !worlds || !missions || !param || !plans) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RBP_ERR_NO_DEVICE, "no HIP device: the RBP path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(RBP_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    const int N = plans[0].N, M = plans[0].M, MB = plans[0].max_boxes;
+    if (N <= 0 || M < 2 || MB <= 0) return fail(RBP_ERR_BAD_ARGUMENT, "need N >= 1, M >= 2, max_boxes >= 1");
+    for (int k = 0; k < K; ++k) {
+        if (plans[k].N != N || plans[k].M != M || plans[k].max_boxes != MB || missions[k].N != N)
+            return fail(RBP_ERR_BAD_ARGUMENT, "all missions of a session must share N, M and max_boxes");
+        if (!plans[k].T || !plans[k].init_traj || !worlds[k].dist)
+            return fail(RBP_ERR_BAD_ARGUMENT, "plan.T / plan.init_traj / world.dist must be set");
+    }
+    if (param->n != 5 || param->phi != 3) return fail(RBP_ERR_UNSUPPORTED_DEGREE, "RBPPlanner: n should be 5, phi 3");
+    auto* s = new rbp_session();
+    s->device = device;
+    s->param = *param;
+    const int P = M + 1, npair = N * (N - 1) / 2, oq = 6 * M;
+    // effective batch size (setBatch, rbp_planner.hpp:849-872)
+    int bs = param->sequential ? param->batch_size : N;
+    if (bs <= 0) bs = 1;
+    if (bs > N) bs = N;
+    s->qp_ws_per_mission = planner_workspace_bytes(N, M, bs);
+
+    size_t grid_bytes = 0;
+    for (int k = 0; k < K; ++k) grid_bytes += al(sizeof(float) * (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2]);
+    size_t total = grid_bytes + al(sizeof(DevWorld) * K) + al(sizeof(float) * (size_t)K * N * P * 3) + al(sizeof(double) * K * P) +
+                   2 * al(sizeof(double) * (size_t)K * N * 9) + al(sizeof(double) * K * N) +
+                   2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) +
+                   al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
+                   al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
+                   2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
+                   al(sizeof(unsigned long long) * K * CT_N) + al(s->qp_ws_per_mission * K) + 4096;
+    hipError_t e = hipMalloc((void**)&s->arena.base, total);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(RBP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    s->arena.size = total;
+    DevSession& d = s->d;
+    d.K = K, d.N = N, d.M = M, d.max_boxes = MB, d.npair = npair;
+    for (int a = 0; a < 3; ++a) d.p.world_min[a] = param->world_min[a], d.p.world_max[a] = param->world_max[a];
+    d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
+    d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
+    d.p.iteration = param->iteration, d.p.time_scale = param->time_scale;
+
+    Arena& A = s->arena;
+    s->worlds_h.resize(K);
+#define UP(dst, src, bytes) HIP_TRY(hipMemcpy((void*)(dst), (src), (bytes), hipMemcpyHostToDevice))
+    for (int k = 0; k < K; ++k) {
+        size_t n = (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2];
+        float* g = A.take<float>(n);
+        UP(g, worlds[k].dist, sizeof(float) * n);
+        DevWorld& w = s->worlds_h[k];
+        for (int a = 0; a < 3; ++a) w.dim[a] = worlds[k].dim[a], w.key_min[a] = worlds[k].key_min[a];
+        w.res = worlds[k].res;
+        w.dist = g;
+    }
+    DevWorld* dw = A.take<DevWorld>(K);
+    UP(dw, s->worlds_h.data(), sizeof(DevWorld) * K);
+    d.worlds = dw;
+    float* traj = A.take<float>((size_t)K * N * P * 3);
+    double* T = A.take<double>((size_t)K * P);
+    double* start = A.take<double>((size_t)K * N * 9);
+    double* goal = A.take<double>((size_t)K * N * 9);
+    double* radius = A.take<double>((size_t)K * N);
+    double* mv = A.take<double>((size_t)K * N * 3);
+    double* ma = A.take<double>((size_t)K * N * 3);
+    d.sfc_count = A.take<int>((size_t)K * N);
+    d.sfc_box = A.take<double>((size_t)K * N * MB * 6);
+    d.sfc_time = A.take<double>((size_t)K * N * MB);
+    d.rsfc_normal = A.take<float>((size_t)K * npair * M * 3 + 4);
+    d.rsfc_time = A.take<double>((size_t)K * M);
+    d.ctrl = A.take<double>((size_t)K * N * 3 * oq);
+    d.coef = A.take<double>((size_t)K * N * 3 * oq);
+    d.status = A.take<int>(K);
+    d.scalars = A.take<double>((size_t)K * SC_N);
+    d.counters = A.take<unsigned long long>((size_t)K * CT_N);
+    s->qp_ws = A.take<char>(s->qp_ws_per_mission * K);
+    if (A.off > A.size) {
+        rbp_session_destroy(s);
+        return fail(RBP_ERR_HIP, "arena overflow (internal sizing error)");
+    }
+    s->T0.resize((size_t)K * P);
+    bool have_corr = true;
+    for (int k = 0; k < K; ++k)
+        have_corr = have_corr && plans[k].sfc_count && plans[k].sfc_box && plans[k].sfc_time && plans[k].rsfc_normal && plans[k].rsfc_time;
+    s->have_corridor_inputs = have_corr;
+    if (have_corr) {
+        s->sfc_count0.resize((size_t)K * N), s->sfc_box0.resize((size_t)K * N * MB * 6), s->sfc_time0.resize((size_t)K * N * MB);
+        s->rsfc_normal0.resize((size_t)K * npair * M * 3), s->rsfc_time0.resize((size_t)K * M);
+    }
+    for (int k = 0; k < K; ++k) {
+        UP(traj + (size_t)k * N * P * 3, plans[k].init_traj, sizeof(float) * (size_t)N * P * 3);
+        UP(T + (size_t)k * P, plans[k].T, sizeof(double) * P);
+        memcpy(&s->T0[(size_t)k * P], plans[k].T, sizeof(double) * P);
+        UP(start + (size_t)k * N * 9, missions[k].start, sizeof(double) * N * 9);
+        UP(goal + (size_t)k * N * 9, missions[k].goal, sizeof(double) * N * 9);
+        UP(radius + (size_t)k * N, missions[k].radius, sizeof(double) * N);
+        UP(mv + (size_t)k * N * 3, missions[k].max_vel, sizeof(double) * N * 3);
+        UP(ma + (size_t)k * N * 3, missions[k].max_acc, sizeof(double) * N * 3);
+        if (have_corr) {
+            memcpy(&s->sfc_count0[(size_t)k * N], plans[k].sfc_count, sizeof(int) * N);
+            memcpy(&s->sfc_box0[(size_t)k * N * MB * 6], plans[k].sfc_box, sizeof(double) * (size_t)N * MB * 6);
+            memcpy(&s->sfc_time0[(size_t)k * N * MB], plans[k].sfc_time, sizeof(double) * (size_t)N * MB);
+            memcpy(&s->rsfc_normal0[(size_t)k * npair * M * 3], plans[k].rsfc_normal, sizeof(float) * (size_t)npair * M * 3);
+            memcpy(&s->rsfc_time0[(size_t)k * M], plans[k].rsfc_time, sizeof(double) * M);
+        }
+    }
+    d.init_traj = traj, d.T = T, d.start = start, d.goal = goal, d.radius = radius, d.max_vel = mv, d.max_acc = ma;
+#undef UP
+    int rc = rbp_session_reset(s, nullptr);
+    if (rc) {
+        rbp_session_destroy(s);
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    *out = s;
+    return RBP_OK;
+}
+
+int rbp_session_reset(rbp_session* s, void* stream) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    hipStream_t st = (hipStream_t)stream;
+    const DevSession& d = s->d;
+    const int K = d.K, N = d.N, M = d.M, MB = d.max_boxes;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(d.T, s->T0.data(), sizeof(double) * s->T0.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int) * K, st));
+    HIP_TRY(hipMemsetAsync(d.scalars, 0, sizeof(double) * K * SC_N, st));
+    HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * K * CT_N, st));
+    if (s->have_corridor_inputs) {
+        HIP_TRY(hipMemcpyAsync(d.sfc_count, s->sfc_count0.data(), sizeof(int) * (size_t)K * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.sfc_box, s->sfc_box0.data(), sizeof(double) * (size_t)K * N * MB * 6, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.sfc_time, s->sfc_time0.data(), sizeof(double) * (size_t)K * N * MB, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.rsfc_normal, s->rsfc_normal0.data(), sizeof(float) * (size_t)K * d.npair * M * 3, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d.rsfc_time, s->rsfc_time0.data(), sizeof(double) * (size_t)K * M, hipMemcpyHostToDevice, st));
+    }
+    return RBP_OK;
+}
+
+int rbp_session_run(rbp_session* s, int stages, void* stream) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(s->device));
+    if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
+    if (stages & RBP_STAGE_PLANNER) launch_planner(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+    HIP_TRY(hipGetLastError());
+    return RBP_OK;
+}
+
+int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream) {
+    if (!s || !plans) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const DevSession& d = s->d;
+    const int K = d.K, N = d.N, M = d.M, MB = d.max_boxes, P = M + 1, oq = 6 * M;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int> stat(K);
+    std::vector<double> sc((size_t)K * SC_N);
+#define DN(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (const void*)(src), (bytes), hipMemcpyDeviceToHost))
+    DN(stat.data(), d.status, sizeof(int) * K);
+    DN(sc.data(), d.scalars, sizeof(double) * K * SC_N);
+    int first = 0;
+    // setBatch bookkeeping for the size fields (rbp_planner.hpp:58-60): last batch solved
+    int bs = s->param.sequential ? s->param.batch_size : N;
+    if (bs <= 0) bs = 1;
+    if (bs > N) bs = N;
+    int bmax = (N + bs - 1) / bs;
+    int biter = s->param.sequential ? s->param.batch_iter : 1;
+    if (s->param.sequential && (biter < 0 || biter > bmax)) biter = bmax;
+    for (int k = 0; k < K; ++k) {
+        rbp_plan& p = plans[k];
+        if (p.N != N || p.M != M || p.max_boxes != MB) return fail(RBP_ERR_BAD_ARGUMENT, "plan shape differs from the session");
+        DN(p.T, d.T + (size_t)k * P, sizeof(double) * P);
+        if (p.sfc_count) DN(p.sfc_count, d.sfc_count + (size_t)k * N, sizeof(int) * N);
+        if (p.sfc_box) DN(p.sfc_box, d.sfc_box + (size_t)k * N * MB * 6, sizeof(double) * (size_t)N * MB * 6);
+        if (p.sfc_time) DN(p.sfc_time, d.sfc_time + (size_t)k * N * MB, sizeof(double) * (size_t)N * MB);
+        if (p.rsfc_normal) DN(p.rsfc_normal, d.rsfc_normal + (size_t)k * d.npair * M * 3, sizeof(float) * (size_t)d.npair * M * 3);
+        if (p.rsfc_time) DN(p.rsfc_time, d.rsfc_time + (size_t)k * M, sizeof(double) * M);
+        if (p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oq);
+        if (p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oq);
+        const double* q = &sc[(size_t)k * SC_N];
+        p.time_scale = q[SC_TIME_SCALE] > 0 ? q[SC_TIME_SCALE] : 1.0;
+        p.total_cost = q[SC_TOTAL_COST];
+        p.qp_iterations = (int)q[SC_IPM_ITERS];
+        if (biter > 0) {
+            int last = biter - 1, nb = std::min(bs, N - last * bs);
+            p.x_size = 3 * nb * oq;
+            p.eq_size = 3 * nb * 3 * (M + 1);
+            int nf = N - nb;
+            p.ineq_size = 2 * p.x_size + (nb * (nb - 1) / 2 + nb * nf) * oq;
+        }
+        if (status) status[k] = stat[k];
+        if (!first && stat[k]) first = stat[k];
+    }
+#undef DN
+    if (first) g_err = "mission failed with status " + std::to_string(first);
+    return first;
+}
+
+int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
+    if (!s || !out) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const int K = s->d.K;
+    std::vector<unsigned long long> ct((size_t)K * CT_N);
+    std::vector<double> sc((size_t)K * SC_N);
+    HIP_TRY(hipMemcpy(ct.data(), s->d.counters, sizeof(unsigned long long) * ct.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sc.data(), s->d.scalars, sizeof(double) * sc.size(), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    for (int k = 0; k < K; ++k) {
+        out->sfc_samples += (double)ct[(size_t)k * CT_N + CT_SFC_SAMPLES];
+        out->qp_flops += sc[(size_t)k * SC_N + SC_FLOPS];
+        out->qp_ipm_iters += sc[(size_t)k * SC_N + SC_IPM_ITERS];
+        out->qp_solves += sc[(size_t)k * SC_N + SC_QP_SOLVED];
+        out->qp_constraint_rows += sc[(size_t)k * SC_N + SC_ROWS];
+    }
+    return RBP_OK;
+}
+
+void rbp_session_destroy(rbp_session* s) {
+    if (!s) return;
+    if (s->arena.base) {
+        (void)hipSetDevice(s->device);
+        (void)hipFree(s->arena.base);
+    }
+    delete s;
+}
+
+static int one_shot(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan, int stages) {
+    if (!mission || !param || !plan) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    rbp_world dummy_world;
+    float zero = 0.0f;
+    if (!world) {  // planner stage does not read the map
+        dummy_world.dim[0] = dummy_world.dim[1] = dummy_world.dim[2] = 1;
+        dummy_world.key_min[0] = dummy_world.key_min[1] = dummy_world.key_min[2] = 0;
+        dummy_world.res = 1.0, dummy_world.dist = &zero;
+        world = &dummy_world;
+    }
+    rbp_session* s = nullptr;
+    int rc = rbp_session_create(&s, 0, 1, world, mission, param, plan);
+    if (rc) return rc;
+    rc = rbp_session_run(s, stages, nullptr);
+    if (!rc) {
+        int32_t st = 0;
+        rc = rbp_session_download(s, plan, &st, nullptr);
+    }
+    rbp_session_destroy(s);
+    return rc;
+}
+
+int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
+    if (!world) return fail(RBP_ERR_BAD_ARGUMENT, "null world");
+    return one_shot(world, mission, param, plan, RBP_STAGE_CORRIDOR);
+}
+
+int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
+    return one_shot(nullptr, mission, param, plan, RBP_STAGE_PLANNER);
+}
+
+}  // extern "C"

@@ -1,0 +1,1071 @@
+// qp.hip — the batched RBP QP on gfx950: assembly, interior-point solve, epilogue.
+//
+// Replaces RBPPlanner::update (reference: swarm_planner/include/rbp_planner.hpp:33-84): buildConstMtx :100-109,
+// populatebyrow :551-688, cplex.solve() :158, the Bernstein->monomial loop :167-196, timeScale :209-266.
+//
+// Formulation (DESIGN.md "QP"): the equality rows of Aeq_base (:353-405) are C2 continuity at the knots plus the
+// pinned end states, so per (agent, dim) and interior knot j the three control points right of the knot are free
+// (u_j) and the three left of it are L_j u_j.  In these coordinates the batch QP has NO equality rows, every
+// inequality row (SFC bound :626-635, RSFC :638-684) touches exactly one knot, and the Newton matrix of a
+// primal-dual interior-point method, F'(2Q)F + J' W J, is block tridiagonal over the M-1 knots with dense
+// blocks of order nk = 9 * (batch agents).  One workgroup solves one mission's batch QP:
+//   * row sweeps (slack, weights, step lengths) stream the row state (s, z) from HBM/L2, coalesced along the
+//     control-point index;
+//   * per-control-point 3x3 accumulators are expanded into the knot blocks (no atomics);
+//   * the block-tridiagonal Cholesky runs knot by knot with the three live nk x nk blocks in LDS.
+// Batches of a mission are solved strictly in the reference's order (Gauss-Seidel, :140-148); parallelism comes
+// from the 3*nb coupled blocks inside a batch and from the K missions of a session.
+#include <algorithm>
+#include <vector>
+
+#include "rbp_dev.h"
+
+#define QP_THREADS 256
+#define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
+#define QP_MAX_ITERS 80
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// dimensions of one batch QP
+// ------------------------------------------------------------------------------------------------------------
+struct QpDims {
+    int N, M, oq;       // agents, segments, 6M
+    int nb, NF, npb;    // batch agents, frozen agents, in-batch pairs
+    int nk, nj, ld;     // block order 9*nb, knots M-1, padded leading dimension
+    int first;          // first agent of the batch (batches are contiguous: qi / batch_size == l)
+    size_t nbnd, nfro, npr, nrows;
+};
+
+__host__ __device__ inline QpDims make_dims(int N, int M, int first, int nb) {
+    QpDims d;
+    d.N = N, d.M = M, d.oq = 6 * M, d.nb = nb, d.NF = N - nb, d.npb = nb * (nb - 1) / 2;
+    d.nk = 9 * nb, d.nj = M - 1, d.ld = d.nk + 1, d.first = first;
+    d.nbnd = (size_t)nb * 6 * d.oq, d.nfro = (size_t)nb * d.NF * d.oq, d.npr = (size_t)d.npb * d.oq;
+    d.nrows = d.nbnd + d.nfro + d.npr;
+    return d;
+}
+
+// workspace (doubles) per mission, sized for the largest batch
+struct QpWs {
+    double *s, *z, *ds, *dz, *cc;   // row state [nrows]
+    double *cpacc;                  // [nb*oq][12]: S(6) yv(3) gz(3) per control point
+    double *pracc;                  // [npb*oq][12]
+    double *dx, *dxa, *cvec;        // [nb*3*oq]
+    double *rbase, *rhs;            // [(M-1)*nk]
+    double *Td, *To;                // [(M-1)][nk*nk], [(M-2)][nk*nk]
+    double *boxlo, *boxhi;          // [nb][M][3]
+    double *Lk, *Dk, *Ek;           // [M+1][9]
+};
+
+__host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
+    QpDims d = make_dims(N, M, 0, nbmax);
+    size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
+               2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + 64;
+    return n;
+}
+
+__device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
+    QpDims dm = make_dims(d.N, d.M, 0, nbmax);
+    QpWs w;
+    double* p = base;
+    w.s = p, p += dm.nrows;
+    w.z = p, p += dm.nrows;
+    w.ds = p, p += dm.nrows;
+    w.dz = p, p += dm.nrows;
+    w.cc = p, p += dm.nrows;
+    w.cpacc = p, p += 12 * (size_t)nbmax * d.oq;
+    w.pracc = p, p += 12 * (size_t)(dm.npb ? dm.npb : 1) * d.oq;
+    w.dx = p, p += (size_t)nbmax * 3 * d.oq;
+    w.dxa = p, p += (size_t)nbmax * 3 * d.oq;
+    w.cvec = p, p += (size_t)nbmax * 3 * d.oq;
+    w.rbase = p, p += (size_t)dm.nj * dm.nk;
+    w.rhs = p, p += (size_t)dm.nj * dm.nk;
+    w.Td = p, p += (size_t)dm.nj * dm.nk * dm.nk;
+    w.To = p, p += (size_t)(dm.nj > 1 ? dm.nj - 1 : 1) * dm.nk * dm.nk;
+    w.boxlo = p, p += (size_t)nbmax * d.M * 3;
+    w.boxhi = p, p += (size_t)nbmax * d.M * 3;
+    w.Lk = p, p += (size_t)(d.M + 1) * 9;
+    w.Dk = p, p += (size_t)(d.M + 1) * 9;
+    w.Ek = p, p += (size_t)(d.M + 1) * 9;
+    return w;
+}
+
+// Q_base (rbp_planner.hpp:330-335) = int_0^1 B'''_i B'''_j
+__constant__ double c_Qbase[36] = {720,  -1800, 1200,  0,     0,     -120, -1800, 4800,  -3600, 0,     600,   0,
+                                   1200, -3600, 3600,  -1200, 0,     0,    0,     0,     -1200, 3600,  -3600, 1200,
+                                   0,    600,   0,     -3600, 4800,  -1800, -120, 0,     0,     1200,  -1800, 720};
+// Bernstein -> monomial, rows = control point, cols = descending powers (rbp_planner.hpp:338-343)
+__constant__ double c_basis[36] = {-1, 5,   -10, 10, -5, 1, 5,  -20, 30, -20, 5, 0, -10, 30, -30, 10, 0, 0,
+                                   10, -20, 10,  0,  0,  0, -5, 5,   0,  0,   0, 0, 1,   0,  0,   0,  0, 0};
+
+__device__ inline size_t pair_index(int N, int qi, int qj) { return (size_t)qi * N - (size_t)qi * (qi + 1) / 2 + (qj - qi - 1); }
+
+// ---- block reductions ------------------------------------------------------------------------------------------
+__device__ inline double block_reduce(double v, int op /*0 sum,1 max,2 min*/, double* red) {
+    for (int o = 32; o > 0; o >>= 1) {
+        double t = __shfl_xor(v, o);
+        v = op == 0 ? v + t : (op == 1 ? fmax(v, t) : fmin(v, t));
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < QP_THREADS / 64; ++i) r = op == 0 ? r + red[i] : (op == 1 ? fmax(r, red[i]) : fmin(r, red[i]));
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-mission constants: L_j (continuity map), D_j = L_j'(2Q22)L_j + 2Q11, E_j = 2 Q12 L_{j+1}
+// Aeq_base rows at knot j (rbp_planner.hpp:390-399):  dl^-i nn_i A_T.row(i) c_{j-1} = dr^-i nn_i A_0.row(i) c_j
+// ------------------------------------------------------------------------------------------------------------
+__device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
+    const int M = d.M;
+    for (int j = threadIdx.x; j <= M; j += QP_THREADS) {
+        double* L = w.Lk + 9 * j;
+        for (int e = 0; e < 9; ++e) L[e] = 0;
+        if (j >= 1 && j < M) {
+            const double r = (T[j] - T[j - 1]) / (T[j + 1] - T[j]);  // dl / dr
+            // c5 = u0 ; c4 = c5 - r (u1 - u0) ; c3 = 2 c4 - c5 + r^2 (u0 - 2 u1 + u2)   (rows: c3, c4, c5)
+            L[0] = (1 + r) * (1 + r), L[1] = -2 * r * (1 + r), L[2] = r * r;
+            L[3] = 1 + r, L[4] = -r, L[5] = 0;
+            L[6] = 1, L[7] = 0, L[8] = 0;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j <= M; j += QP_THREADS) {
+        double* D = w.Dk + 9 * j;
+        double* E = w.Ek + 9 * j;
+        for (int e = 0; e < 9; ++e) D[e] = 0, E[e] = 0;
+        if (j >= 1 && j < M) {
+            const double sl = pow(T[j] - T[j - 1], -5.0), sr = pow(T[j + 1] - T[j], -5.0);  // build_Q_p :349-351
+            const double* L = w.Lk + 9 * j;
+            double QL[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double s = 0;
+                    for (int c = 0; c < 3; ++c) s += c_Qbase[6 * (3 + a) + 3 + c] * sl * L[3 * c + b];
+                    QL[3 * a + b] = s;
+                }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double s = 0;
+                    for (int c = 0; c < 3; ++c) s += L[3 * c + a] * QL[3 * c + b];
+                    D[3 * a + b] = 2 * (s + c_Qbase[6 * a + b] * sr);
+                }
+            if (j + 1 < M) {
+                const double* Ln = w.Lk + 9 * (j + 1);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        double s = 0;
+                        for (int c = 0; c < 3; ++c) s += c_Qbase[6 * a + 3 + c] * sr * Ln[3 * c + b];
+                        E[3 * a + b] = 2 * s;  // rows u_j, cols u_{j+1}
+                    }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// row sweeps.  Rows of a batch QP (G x <= h form, as in the oracle):
+//   bound   (a,k,side,j6):  +x <= hi   /  -x <= -lo                       rbp_planner.hpp:626-635
+//   frozen  (a,f,j6):       sg * n . x_a <= -rr + sg * n . dummy_f        :645-666   sg = +1 if a < f else -1
+//   pair    (a<b,j6):       n . x_a - n . x_b <= -rr                      :668-679
+// Control points j6 < 3 and j6 >= 6M-3 are pinned by the end-state equalities: their rows are constants and are
+// only checked once (presolve).  Work item = one free control point of one batch agent (all its bound and frozen
+// rows), then one (pair, control point).
+// ------------------------------------------------------------------------------------------------------------
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE };
+
+struct PassIO {
+    // inputs
+    double mu0, s_floor, dreg, sigma_mu, alpha;
+    // outputs (block-reduced by the caller)
+    double sum0, sum1, sum2, vmax, vmin;
+};
+
+struct RowCtx {
+    const DevSession* S;
+    int mission;
+    QpDims d;
+    QpWs w;
+    const double* ctrl;  // [N][3][oq] of this mission
+    const float* normals;  // [npair][M][3]
+    const double* radius;  // [N]
+};
+
+template <int PASS>
+__device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, size_t r, const QpWs& w, PassIO& io,
+                                       double& wgt, double& v) {
+    // slack = h - g.x ; returns weight wgt and rhs scalar v where relevant
+    if (PASS == PASS_INIT) {
+        double s = slack < io.s_floor ? io.s_floor : slack;
+        w.s[r] = s;
+        w.z[r] = io.mu0 / s;
+    } else if (PASS == PASS_BUILD) {
+        const double s = w.s[r], z = w.z[r];
+        const double rg = s - slack;
+        wgt = 1.0 / (s / z + io.dreg);
+        v = -wgt * (rg - s);  // predictor: rc / z = s
+        io.sum0 += s * z;
+        io.vmax = fmax(io.vmax, fabs(rg));
+    } else if (PASS == PASS_AFF) {
+        const double s = w.s[r], z = w.z[r];
+        const double rg = s - slack;
+        wgt = 1.0 / (s / z + io.dreg);
+        const double dza = wgt * (gdx_a + rg - s);
+        const double dsa = (-s * z - s * dza) / z;
+        w.cc[r] = dsa * dza;
+        if (dsa < 0) io.vmin = fmin(io.vmin, -s / dsa);
+        if (dza < 0) io.vmin = fmin(io.vmin, -z / dza);
+        io.sum0 += s * z, io.sum1 += s * dza + z * dsa, io.sum2 += dsa * dza;
+    } else if (PASS == PASS_CORR_RHS) {
+        const double s = w.s[r], z = w.z[r];
+        const double rg = s - slack;
+        wgt = 1.0 / (s / z + io.dreg);
+        const double rcc = s * z + w.cc[r] - io.sigma_mu;
+        v = -wgt * (rg - rcc / z);
+    } else if (PASS == PASS_STEP) {
+        const double s = w.s[r], z = w.z[r];
+        const double rg = s - slack;
+        wgt = 1.0 / (s / z + io.dreg);
+        const double rcc = s * z + w.cc[r] - io.sigma_mu;
+        const double dz = wgt * (gdx + rg - rcc / z);
+        const double ds = (-rcc - s * dz) / z;
+        w.ds[r] = ds, w.dz[r] = dz;
+        if (ds < 0) io.vmin = fmin(io.vmin, -s / ds);
+        if (dz < 0) io.vmin = fmin(io.vmin, -z / dz);
+    } else if (PASS == PASS_NBHD) {
+        const double p = (w.s[r] + io.alpha * w.ds[r]) * (w.z[r] + io.alpha * w.dz[r]);
+        io.sum0 += p;
+        io.vmin = fmin(io.vmin, p);
+    } else if (PASS == PASS_UPDATE) {
+        w.s[r] += io.alpha * w.ds[r];
+        w.z[r] += io.alpha * w.dz[r];
+    } else if (PASS == PASS_PRESOLVE) {
+        io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
+    }
+}
+
+template <int PASS>
+__device__ void row_pass(const RowCtx& c, PassIO& io) {
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const int oq = d.oq, N = d.N;
+    constexpr bool accum = (PASS == PASS_BUILD || PASS == PASS_CORR_RHS);
+    constexpr bool pinned_only = (PASS == PASS_PRESOLVE);
+    // ---- control points of batch agents: bound + frozen rows
+    const int ncp = d.nb * oq;
+    for (int it = threadIdx.x; it < ncp; it += QP_THREADS) {
+        const int a = it / oq, j6 = it % oq, seg = j6 / 6;
+        const bool pinned = (j6 < 3 || j6 >= oq - 3);
+        if (pinned != pinned_only) continue;
+        const int qa = d.first + a;
+        double xa[3], da[3], dd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xa[k] = c.ctrl[((size_t)qa * 3 + k) * oq + j6];
+            da[k] = (PASS == PASS_AFF) ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = (PASS == PASS_STEP) ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+        }
+        double S[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
+        // bounds
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double hi = w.boxhi[((size_t)a * d.M + seg) * 3 + k], lo = w.boxlo[((size_t)a * d.M + seg) * 3 + k];
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const size_t r = ((size_t)(a * 3 + k) * 2 + side) * oq + j6;
+                const double sg = side == 0 ? 1.0 : -1.0;
+                const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
+                double wgt = 0, v = 0;
+                row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, wgt, v);
+                if (accum) {
+                    const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);  // diagonal slots of the packed 3x3
+                    if (PASS == PASS_BUILD) {
+                        S[dg] += wgt;
+                        gz[k] += sg * w.z[r];
+                    }
+                    yv[k] += sg * v;
+                }
+            }
+        }
+        // frozen neighbours
+        const double ra = c.radius[qa];
+        int fi = 0;
+        for (int f = 0; f < N; ++f) {
+            if (f >= d.first && f < d.first + d.nb) continue;
+            const size_t r = d.nbnd + ((size_t)a * d.NF + fi) * oq + j6;
+            ++fi;
+            const bool a_first = qa < f;
+            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * d.M + seg) * 3;
+            const double sg = a_first ? 1.0 : -1.0;
+            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
+            const double f0 = c.ctrl[((size_t)f * 3 + 0) * oq + j6], f1 = c.ctrl[((size_t)f * 3 + 1) * oq + j6],
+                         f2 = c.ctrl[((size_t)f * 3 + 2) * oq + j6];
+            const double slack = n0 * (f0 - xa[0]) + n1 * (f1 - xa[1]) + n2 * (f2 - xa[2]) - (ra + c.radius[f]);
+            double wgt = 0, v = 0;
+            row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
+            if (accum) {
+                if (PASS == PASS_BUILD) {
+                    S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
+                    S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
+                    const double z = w.z[r];
+                    gz[0] += z * n0, gz[1] += z * n1, gz[2] += z * n2;
+                }
+                yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+            }
+        }
+        if (accum) {
+            double* acc = w.cpacc + (size_t)it * 12;
+            if (PASS == PASS_BUILD) {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) acc[e] = S[e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc[9 + e] = gz[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e];
+        }
+    }
+    // ---- in-batch pairs
+    const int npi = d.npb * oq;
+    for (int it = threadIdx.x; it < npi; it += QP_THREADS) {
+        const int pr = it / oq, j6 = it % oq, seg = j6 / 6;
+        const bool pinned = (j6 < 3 || j6 >= oq - 3);
+        if (pinned != pinned_only) continue;
+        int a = 0, rem = pr;
+        while (rem >= d.nb - 1 - a) rem -= d.nb - 1 - a, a++;
+        const int b = a + 1 + rem;
+        const int qa = d.first + a, qb = d.first + b;
+        const size_t r = d.nbnd + d.nfro + (size_t)pr * oq + j6;
+        const float* nv = c.normals + (pair_index(N, qa, qb) * d.M + seg) * 3;
+        const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
+        double e0 = c.ctrl[((size_t)qb * 3 + 0) * oq + j6] - c.ctrl[((size_t)qa * 3 + 0) * oq + j6];
+        double e1 = c.ctrl[((size_t)qb * 3 + 1) * oq + j6] - c.ctrl[((size_t)qa * 3 + 1) * oq + j6];
+        double e2 = c.ctrl[((size_t)qb * 3 + 2) * oq + j6] - c.ctrl[((size_t)qa * 3 + 2) * oq + j6];
+        const double slack = n0 * e0 + n1 * e1 + n2 * e2 - (c.radius[qa] + c.radius[qb]);
+        double ga = 0, gd = 0;
+        if (PASS == PASS_AFF) {
+            ga = n0 * (w.dxa[((size_t)a * 3 + 0) * oq + j6] - w.dxa[((size_t)b * 3 + 0) * oq + j6]) +
+                 n1 * (w.dxa[((size_t)a * 3 + 1) * oq + j6] - w.dxa[((size_t)b * 3 + 1) * oq + j6]) +
+                 n2 * (w.dxa[((size_t)a * 3 + 2) * oq + j6] - w.dxa[((size_t)b * 3 + 2) * oq + j6]);
+        }
+        if (PASS == PASS_STEP) {
+            gd = n0 * (w.dx[((size_t)a * 3 + 0) * oq + j6] - w.dx[((size_t)b * 3 + 0) * oq + j6]) +
+                 n1 * (w.dx[((size_t)a * 3 + 1) * oq + j6] - w.dx[((size_t)b * 3 + 1) * oq + j6]) +
+                 n2 * (w.dx[((size_t)a * 3 + 2) * oq + j6] - w.dx[((size_t)b * 3 + 2) * oq + j6]);
+        }
+        double wgt = 0, v = 0;
+        row_op<PASS>(slack, ga, gd, r, w, io, wgt, v);
+        if (accum) {
+            double* acc = w.pracc + (size_t)it * 12;
+            if (PASS == PASS_BUILD) {
+                acc[0] = wgt * n0 * n0, acc[1] = wgt * n0 * n1, acc[2] = wgt * n0 * n2;
+                acc[3] = wgt * n1 * n1, acc[4] = wgt * n1 * n2, acc[5] = wgt * n2 * n2;
+                const double z = w.z[r];
+                acc[9] = z * n0, acc[10] = z * n1, acc[11] = z * n2;
+            }
+            acc[6] = v * n0, acc[7] = v * n1, acc[8] = v * n2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// control-space <-> reduced-space maps
+// ------------------------------------------------------------------------------------------------------------
+// cvec[a][k][j6] (control space)  ->  out[(j-1)*nk + (a*3+k)*3 + e] = (F' cvec)
+__device__ void apply_FT(const QpDims& d, const QpWs& w, const double* cvec, double* out, double scale) {
+    const int oq = d.oq, nu = 3 * d.nb;
+    for (int it = threadIdx.x; it < d.nj * nu; it += QP_THREADS) {
+        const int j = it / nu + 1, u = it % nu;
+        const double* xr = cvec + (size_t)u * oq + 6 * j;
+        const double* xl = cvec + (size_t)u * oq + 6 * (j - 1) + 3;
+        const double* L = w.Lk + 9 * j;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            out[(size_t)(j - 1) * d.nk + u * 3 + e] = scale * (xr[e] + L[0 + e] * xl[0] + L[3 + e] * xl[1] + L[6 + e] * xl[2]);
+    }
+}
+// dx[a][k][j6] = F du   (pinned control points get 0)
+__device__ void apply_F(const QpDims& d, const QpWs& w, const double* du, double* dx) {
+    const int oq = d.oq, nu = 3 * d.nb;
+    for (int it = threadIdx.x; it < nu * oq; it += QP_THREADS) {
+        const int u = it / oq, j6 = it % oq, m = j6 / 6, i = j6 % 6;
+        double v = 0;
+        if (i < 3) {
+            if (m >= 1) v = du[(size_t)(m - 1) * d.nk + u * 3 + i];
+        } else if (m + 1 < d.M) {
+            const double* L = w.Lk + 9 * (m + 1) + 3 * (i - 3);
+            const double* uu = du + (size_t)m * d.nk + u * 3;
+            v = L[0] * uu[0] + L[1] * uu[1] + L[2] * uu[2];
+        }
+        dx[it] = v;
+    }
+}
+
+// cvec = -(2Q x + G'z) in control space, for batch agents; returns via cvec.  gz comes from the BUILD accumulators.
+__device__ void grad_ctrl(const RowCtx& c) {
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const int oq = d.oq;
+    const double* T = c.S->T + (size_t)c.mission * (d.M + 1);
+    for (int it = threadIdx.x; it < d.nb * 3 * oq; it += QP_THREADS) {
+        const int a = it / (3 * oq), k = (it / oq) % 3, j6 = it % oq, m = j6 / 6, i = j6 % 6;
+        if (j6 < 3 || j6 >= oq - 3) {  // pinned control point: not a variable
+            w.cvec[it] = 0;
+            continue;
+        }
+        const double sc = pow(T[m + 1] - T[m], -5.0);
+        const double* xs = c.ctrl + ((size_t)(d.first + a) * 3 + k) * oq + 6 * m;
+        double g = 0;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) g += c_Qbase[6 * i + jj] * xs[jj];
+        g *= 2 * sc;
+        // G'z: own control-point accumulator + pair accumulators
+        g += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];
+        int pr = 0;
+        for (int p = 0; p < d.nb; ++p)
+            for (int q = p + 1; q < d.nb; ++q, ++pr) {
+                if (p == a) g += w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
+                if (q == a) g -= w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
+            }
+        w.cvec[it] = -g;
+    }
+}
+// cvec = G'v in control space (yv accumulators)
+__device__ void gtv_ctrl(const RowCtx& c) {
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const int oq = d.oq;
+    for (int it = threadIdx.x; it < d.nb * 3 * oq; it += QP_THREADS) {
+        const int a = it / (3 * oq), k = (it / oq) % 3, j6 = it % oq;
+        if (j6 < 3 || j6 >= oq - 3) {
+            w.cvec[it] = 0;
+            continue;
+        }
+        double g = w.cpacc[((size_t)a * oq + j6) * 12 + 6 + k];
+        int pr = 0;
+        for (int p = 0; p < d.nb; ++p)
+            for (int q = p + 1; q < d.nb; ++q, ++pr) {
+                if (p == a) g += w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
+                if (q == a) g -= w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
+            }
+        w.cvec[it] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// knot blocks:  T_j = blockdiag(D_j) + sum_p S_p (x) t_p t_p',   T_{j+1,j} = blockdiag(E_j')
+// ------------------------------------------------------------------------------------------------------------
+__device__ inline double sym3(const double* S, int k, int l) {
+    const int a = k < l ? k : l, b = k < l ? l : k;
+    return S[a == 0 ? b : (a == 1 ? 2 + b : 5)];
+}
+
+__device__ void assemble_blocks(const RowCtx& c) {
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const int nk = d.nk, oq = d.oq, nb = d.nb;
+    const size_t nent = (size_t)d.nj * nk * nk;
+    for (size_t it = threadIdx.x; it < nent; it += QP_THREADS) {
+        const int j = (int)(it / ((size_t)nk * nk)) + 1;
+        const int rr = (int)(it % ((size_t)nk * nk)) / nk, cc = (int)(it % ((size_t)nk * nk)) % nk;
+        const int a = rr / 9, k = (rr / 3) % 3, e = rr % 3;
+        const int b = cc / 9, l = (cc / 3) % 3, f = cc % 3;
+        const double* L = w.Lk + 9 * j;
+        double acc = 0;
+        for (int p = 0; p < 6; ++p) {
+            const int j6 = 6 * (j - 1) + 3 + p;
+            const double te = p < 3 ? L[3 * p + e] : (p - 3 == e ? 1.0 : 0.0);
+            const double tf = p < 3 ? L[3 * p + f] : (p - 3 == f ? 1.0 : 0.0);
+            if (te == 0.0 || tf == 0.0) continue;
+            double s = 0;
+            if (a == b) {
+                s = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
+                int pr = 0;
+                for (int p1 = 0; p1 < nb; ++p1)
+                    for (int q1 = p1 + 1; q1 < nb; ++q1, ++pr)
+                        if (p1 == a || q1 == a) s += sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+            } else {
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                const int pr = lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1);
+                s = -sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+            }
+            acc += s * te * tf;
+        }
+        if (a == b && k == l) acc += w.Dk[9 * j + 3 * e + f];
+        w.Td[it] = acc;
+    }
+    if (d.nj > 1) {
+        const size_t noff = (size_t)(d.nj - 1) * nk * nk;
+        for (size_t it = threadIdx.x; it < noff; it += QP_THREADS) {
+            const int j = (int)(it / ((size_t)nk * nk)) + 1;  // couples knot j (cols) and j+1 (rows)
+            const int rr = (int)(it % ((size_t)nk * nk)) / nk, cc = (int)(it % ((size_t)nk * nk)) % nk;
+            double v = 0;
+            if (rr / 3 == cc / 3) v = w.Ek[9 * j + 3 * (cc % 3) + (rr % 3)];  // E_j' : rows u_{j+1}, cols u_j
+            w.To[it] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// block-tridiagonal Cholesky, blocks staged in LDS (padded leading dimension ld = nk + 1)
+//   lds A : current diagonal block / its factor ;  lds B : L_{j,j-1} ;  lds C : T_{j+1,j} -> L_{j+1,j}
+// returns false if a pivot is not positive
+// ------------------------------------------------------------------------------------------------------------
+__device__ bool factor_blocks(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
+    const int nk = d.nk, ld = d.ld, tid = threadIdx.x;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int j = 0; j < d.nj; ++j) {
+        double* Dg = w.Td + (size_t)j * nk * nk;
+        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
+        if (j + 1 < d.nj) {
+            const double* Og = w.To + (size_t)j * nk * nk;
+            for (int it = tid; it < nk * nk; it += QP_THREADS) lC[(it / nk) * ld + it % nk] = Og[it];
+        }
+        __syncthreads();
+        if (j > 0) {  // A -= B B'
+            for (int it = tid; it < nk * nk; it += QP_THREADS) {
+                const int r = it / nk, cidx = it % nk;
+                if (cidx > r) continue;
+                double s = 0;
+                for (int k = 0; k < nk; ++k) s += lB[r * ld + k] * lB[cidx * ld + k];
+                lA[r * ld + cidx] -= s;
+            }
+            __syncthreads();
+        }
+        // Cholesky of A by wave 0 (left-looking, lanes over rows; nk <= 72 -> up to 2 rows per lane)
+        if (tid < 64) {
+            for (int cidx = 0; cidx < nk; ++cidx) {
+                for (int r = cidx + tid; r < nk; r += 64) {
+                    double s = lA[r * ld + cidx];
+                    for (int k = 0; k < cidx; ++k) s -= lA[r * ld + k] * lA[cidx * ld + k];
+                    lA[r * ld + cidx] = s;  // unscaled
+                }
+                __builtin_amdgcn_wave_barrier();
+                const double dd = lA[cidx * ld + cidx];
+                if (!(dd > 0)) {
+                    if (tid == 0) *flag = 1;
+                    break;
+                }
+                const double inv = 1.0 / sqrt(dd);
+                __builtin_amdgcn_wave_barrier();
+                for (int r = cidx + tid; r < nk; r += 64) lA[r * ld + cidx] *= inv;  // diag becomes sqrt(dd)
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (*flag) return false;
+        // C <- C A^{-T}: each row of C independently (forward substitution along columns)
+        if (j + 1 < d.nj) {
+            for (int r = tid; r < nk; r += QP_THREADS) {
+                for (int cidx = 0; cidx < nk; ++cidx) {
+                    double s = lC[r * ld + cidx];
+                    for (int k = 0; k < cidx; ++k) s -= lC[r * ld + k] * lA[cidx * ld + k];
+                    lC[r * ld + cidx] = s / lA[cidx * ld + cidx];
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < nk * nk; it += QP_THREADS) Dg[it] = lA[(it / nk) * ld + it % nk];
+        if (j + 1 < d.nj) {
+            double* Og = w.To + (size_t)j * nk * nk;
+            for (int it = tid; it < nk * nk; it += QP_THREADS) {
+                const double v = lC[(it / nk) * ld + it % nk];
+                Og[it] = v;
+                lB[(it / nk) * ld + it % nk] = v;
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// solve T du = rhs in place (rhs in global, one nk-vector per knot); lv = LDS scratch of 2*nk doubles
+__device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double* lv) {
+    const int nk = d.nk, tid = threadIdx.x;
+    double* cur = lv;
+    double* prev = lv + nk;
+    for (int j = 0; j < d.nj; ++j) {  // forward
+        const double* Dg = w.Td + (size_t)j * nk * nk;
+        for (int r = tid; r < nk; r += QP_THREADS) {
+            double s = rhs[(size_t)j * nk + r];
+            if (j > 0) {
+                const double* Lo = w.To + (size_t)(j - 1) * nk * nk + (size_t)r * nk;
+                for (int k = 0; k < nk; ++k) s -= Lo[k] * prev[k];
+            }
+            cur[r] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {  // forward substitution with the diagonal factor, wave 0, column oriented
+            for (int cidx = 0; cidx < nk; ++cidx) {
+                const double xc = cur[cidx] / Dg[(size_t)cidx * nk + cidx];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) cur[cidx] = xc;
+                for (int r = cidx + 1 + tid; r < nk; r += 64) cur[r] -= Dg[(size_t)r * nk + cidx] * xc;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r], prev[r] = cur[r];
+        __syncthreads();
+    }
+    for (int j = d.nj - 1; j >= 0; --j) {  // backward
+        const double* Dg = w.Td + (size_t)j * nk * nk;
+        for (int cidx = tid; cidx < nk; cidx += QP_THREADS) {
+            double s = rhs[(size_t)j * nk + cidx];
+            if (j + 1 < d.nj) {
+                const double* Lo = w.To + (size_t)j * nk * nk;  // L_{j+1,j}
+                for (int a = 0; a < nk; ++a) s -= Lo[(size_t)a * nk + cidx] * prev[a];
+            }
+            cur[cidx] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {  // back substitution with A' (row oriented on A)
+            for (int cidx = nk - 1; cidx >= 0; --cidx) {
+                const double xc = cur[cidx] / Dg[(size_t)cidx * nk + cidx];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) cur[cidx] = xc;
+                for (int k = tid; k < cidx; k += 64) cur[k] -= Dg[(size_t)cidx * nk + k] * xc;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r], prev[r] = cur[r];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// build_dummy (rbp_planner.hpp:513-549): control points of the waypoint-constant trajectory.  Used as `dummy`
+// in sequential mode and as the interior-point warm start in every mode.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
+    const int M = s.M, P = M + 1, oq = 6 * M;
+    const size_t total = (size_t)s.K * s.N * 3 * oq;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+        const int j6 = (int)(it % oq), k = (int)((it / oq) % 3);
+        const size_t qa = it / ((size_t)3 * oq);  // mission*N + agent
+        const int m = j6 / 6, j = j6 % 6;
+        // idx runs with m (one waypoint pair per segment); the `idx >= size-1` branch is unreachable for M+1 waypoints
+        const float* tr = s.init_traj + qa * P * 3;
+        const int a = (j < 3) ? 0 : 1;
+        s.ctrl[it] = (1 - a) * (double)tr[3 * m + k] + a * (double)tr[3 * (m + 1) + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// one batch QP per workgroup
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int batch,
+                                                               int nbmax, int reset_cost) {
+    const int mission = blockIdx.x, tid = threadIdx.x;
+    if (S.status[mission] != 0) return;
+    const int N = S.N, M = S.M;
+    const int first = batch * nbmax;
+    const int nb = min(nbmax, N - first);
+    if (nb <= 0) return;
+    RowCtx c;
+    c.S = &S, c.mission = mission;
+    c.d = make_dims(N, M, first, nb);
+    c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * c.d.oq;
+    c.ctrl = ctrl;
+    c.normals = S.rsfc_normal + (size_t)mission * S.npair * M * 3;
+    c.radius = S.radius + (size_t)mission * N;
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const double* T = S.T + (size_t)mission * (M + 1);
+    double* scal = S.scalars + (size_t)mission * SC_N;
+
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* lA = lds;
+    double* lB = lA + (size_t)d.nk * d.ld;
+    double* lC = lB + (size_t)d.nk * d.ld;
+    double* lv = lC + (size_t)d.nk * d.ld;  // 2*nk
+    double* red = lv + 2 * d.nk;            // 8
+    int* flag = (int*)(red + 8);
+
+    mission_constants(d, T, const_cast<QpWs&>(w));
+
+    // SFC box of every (batch agent, segment): first box with end time >= T[m+1]  (rbp_planner.hpp:447-453)
+    for (int a = tid; a < nb; a += QP_THREADS) {
+        const int qa = first + a;
+        const int nbx = S.sfc_count[(size_t)mission * N + qa];
+        const double* bt = S.sfc_time + ((size_t)mission * N + qa) * S.max_boxes;
+        const double* bx = S.sfc_box + ((size_t)mission * N + qa) * S.max_boxes * 6;
+        int bi = 0;
+        for (int m = 0; m < M; ++m) {
+            while (bi < nbx && bt[bi] < T[m + 1]) bi++;
+            const int sel = bi < nbx ? bi : nbx - 1;
+            for (int k = 0; k < 3; ++k) {
+                w.boxlo[((size_t)a * M + m) * 3 + k] = bx[6 * sel + k];
+                w.boxhi[((size_t)a * M + m) * 3 + k] = bx[6 * sel + 3 + k];
+            }
+        }
+    }
+    // pin the six end control points of the batch agents to the start/goal state (rows 0-5 of Aeq_base, :380-387)
+    for (int it = tid; it < nb * 3; it += QP_THREADS) {
+        const int a = it / 3, k = it % 3, qa = first + a;
+        const double* st = S.start + ((size_t)mission * N + qa) * 9;
+        const double* gl = S.goal + ((size_t)mission * N + qa) * 9;
+        const double h0 = T[1] - T[0], hT = T[M] - T[M - 1];
+        double* x = ctrl + ((size_t)qa * 3 + k) * d.oq;
+        x[0] = st[k], x[1] = x[0] + h0 * st[k + 3] / 5, x[2] = 2 * x[1] - x[0] + h0 * h0 * st[k + 6] / 20;
+        double* xe = x + 6 * (M - 1);
+        xe[5] = gl[k], xe[4] = xe[5] - hT * gl[k + 3] / 5, xe[3] = 2 * xe[4] - xe[5] + hT * hT * gl[k + 6] / 20;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    PassIO io;
+    io.mu0 = 1e-2, io.s_floor = 1e-2, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
+    // presolve: constant rows (pinned control points) must hold within 1e-6 (CPLEX default feasibility tolerance)
+    io.vmax = 0;
+    row_pass<PASS_PRESOLVE>(c, io);
+    const double pin_viol = block_reduce(io.vmax, 1, red);
+    if (pin_viol > 1e-6) {
+        if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+        return;
+    }
+    row_pass<PASS_INIT>(c, io);
+    __threadfence_block();
+    __syncthreads();
+
+    const double nrows_free = (double)(d.nrows - (size_t)6 * (6 * d.nb + d.nb * d.NF + d.npb));
+    bool ok = false;
+    int it_count = 0;
+    double flops = 0, rows_swept = 0;
+    for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
+        it_count = iter;
+        // ---- sweep 1: weights, accumulators, residual norms
+        io.sum0 = 0, io.vmax = 0;
+        row_pass<PASS_BUILD>(c, io);
+        const double gap = block_reduce(io.sum0, 0, red);
+        const double pres = block_reduce(io.vmax, 1, red);
+        __threadfence_block();
+        __syncthreads();
+        grad_ctrl(c);  // cvec = -(2Qx + G'z)
+        __threadfence_block();
+        __syncthreads();
+        apply_FT(d, w, w.cvec, w.rbase, 1.0);  // rbase = -F'(2Qx + G'z)
+        __threadfence_block();
+        __syncthreads();
+        double dmax = 0, gmax = 0;
+        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) dmax = fmax(dmax, fabs(w.rbase[i]));
+        for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) gmax = fmax(gmax, fabs(w.cvec[i]));
+        const double dres = block_reduce(dmax, 1, red) / (1.0 + block_reduce(gmax, 1, red));
+        const double mu = gap / nrows_free;
+        rows_swept += nrows_free;
+        if (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) {
+            ok = true;
+            break;
+        }
+        // ---- Newton matrix and factorisation
+        assemble_blocks(c);
+        __threadfence_block();
+        __syncthreads();
+        if (!factor_blocks(d, w, lA, lB, lC, flag)) break;
+        flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
+        // ---- predictor
+        gtv_ctrl(c);  // cvec = G'v (v from BUILD)
+        __threadfence_block();
+        __syncthreads();
+        apply_FT(d, w, w.cvec, w.rhs, 1.0);
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
+        __threadfence_block();
+        __syncthreads();
+        solve_blocks(d, w, w.rhs, lv);
+        apply_F(d, w, w.rhs, w.dxa);
+        __threadfence_block();
+        __syncthreads();
+        io.sum0 = io.sum1 = io.sum2 = 0, io.vmin = 1.0;
+        row_pass<PASS_AFF>(c, io);
+        const double a_aff = block_reduce(io.vmin, 2, red);
+        const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
+        const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows_free;
+        double sigma = mu_aff / mu;
+        sigma = sigma * sigma * sigma;
+        io.sigma_mu = sigma * mu;
+        // ---- corrector
+        __threadfence_block();
+        __syncthreads();
+        row_pass<PASS_CORR_RHS>(c, io);
+        __threadfence_block();
+        __syncthreads();
+        gtv_ctrl(c);
+        __threadfence_block();
+        __syncthreads();
+        apply_FT(d, w, w.cvec, w.rhs, 1.0);
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
+        __threadfence_block();
+        __syncthreads();
+        solve_blocks(d, w, w.rhs, lv);
+        apply_F(d, w, w.rhs, w.dx);
+        __threadfence_block();
+        __syncthreads();
+        flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
+        io.vmin = 1e300;
+        row_pass<PASS_STEP>(c, io);
+        double alpha = fmin(1.0, 0.99 * block_reduce(io.vmin, 2, red));
+        __threadfence_block();
+        __syncthreads();
+        // ---- wide neighbourhood: no product below 1e-3 * mu(alpha)
+        for (int bt = 0; bt < 40; ++bt) {
+            io.alpha = alpha, io.sum0 = 0, io.vmin = 1e300;
+            row_pass<PASS_NBHD>(c, io);
+            const double mu_new = block_reduce(io.sum0, 0, red) / nrows_free;
+            const double pmin = block_reduce(io.vmin, 2, red);
+            rows_swept += nrows_free;
+            if (pmin >= 1e-3 * mu_new) break;
+            alpha *= 0.8;
+        }
+        io.alpha = alpha;
+        row_pass<PASS_UPDATE>(c, io);
+        for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
+            const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
+            ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
+        }
+        rows_swept += 5 * nrows_free;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (!ok) {
+        if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+        return;
+    }
+    // objective of this batch: sum x' Q_p x  (cplex.getObjValue, :164)
+    double obj = 0;
+    for (int it = tid; it < d.nb * 3 * M; it += QP_THREADS) {
+        const int a = it / (3 * M), k = (it / M) % 3, m = it % M;
+        const double sc = pow(T[m + 1] - T[m], -5.0);
+        const double* xs = ctrl + ((size_t)(first + a) * 3 + k) * d.oq + 6 * m;
+        double q = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int jj = 0; jj < 6; ++jj) q += c_Qbase[6 * i + jj] * xs[i] * xs[jj];
+        obj += q * sc;
+    }
+    obj = block_reduce(obj, 0, red);
+    if (tid == 0) {
+        if (reset_cost) scal[SC_TOTAL_COST] = 0;
+        scal[SC_TOTAL_COST] += obj;
+        scal[SC_IPM_ITERS] += it_count;
+        scal[SC_QP_SOLVED] += 1;
+        scal[SC_FLOPS] += flops;
+        scal[SC_ROWS] += rows_swept;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// epilogue: Bernstein -> monomial (rbp_planner.hpp:170-196), timeScale (:209-266)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coef_kernel(DevSession s) {
+    const int M = s.M, oq = 6 * M;
+    const size_t total = (size_t)s.K * s.N * 3 * M;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(it % M);
+        const size_t u = it / M;  // (mission*N + agent)*3 + k
+        const int mission = (int)(u / ((size_t)s.N * 3));
+        if (s.status[mission] != 0) continue;
+        const double* T = s.T + (size_t)mission * (M + 1);
+        const double inv = 1.0 / (T[m + 1] - T[m]);
+        const double* v = s.ctrl + u * oq + 6 * m;
+        double* out = s.coef + u * oq + 6 * m;
+        for (int cidx = 0; cidx < 6; ++cidx) {
+            const double tp = pow(inv, 5 - cidx);  // timeMatrix :695-700
+            double acc = 0;
+            for (int i = 0; i < 6; ++i) acc = acc + v[i] * (c_basis[6 * i + cidx] * tp);
+            out[cidx] = acc;
+        }
+    }
+}
+
+__device__ inline int coef_derivative(int i, int j) {  // :721-723
+    int r = 1;
+    for (int t = 0; t < i; ++t) r *= (j - t);
+    return r;
+}
+
+// real roots of c0 t^3 + c1 t^2 + c2 t + c3 after stripping leading zeros (roots_derivative :727-754).
+// DEVIATION shared with the oracle: all real roots are used (the reference inspects the first two eigenvalues of
+// Eigen's companion-matrix solver in Eigen's internal order, which cannot be reproduced without Eigen).
+__device__ int real_roots(const double* cin, int deg, double* out) {
+    const double* c = cin;
+    while (deg > 0 && c[0] == 0) c++, deg--;
+    if (deg == 0) return 0;
+    if (deg == 1) {
+        out[0] = -c[1] / c[0];
+        return 1;
+    }
+    if (deg == 2) {
+        const double D = c[1] * c[1] - 4 * c[0] * c[2];
+        if (D < 0) return 0;
+        const double sq = sqrt(D);
+        out[0] = (-c[1] + sq) / (2 * c[0]), out[1] = (-c[1] - sq) / (2 * c[0]);
+        return 2;
+    }
+    const double a = c[1] / c[0], b = c[2] / c[0], dd = c[3] / c[0];
+    const double p = b - a * a / 3, qq = 2 * a * a * a / 27 - a * b / 3 + dd;
+    const double disc = qq * qq / 4 + p * p * p / 27;
+    int n = 0;
+    if (disc > 0) {
+        const double sq = sqrt(disc);
+        out[n++] = cbrt(-qq / 2 + sq) + cbrt(-qq / 2 - sq) - a / 3;
+    } else if (p == 0) {
+        out[n++] = -a / 3;
+    } else {
+        const double r = sqrt(-p / 3);
+        double arg = 3 * qq / (2 * p * r);
+        arg = fmin(1.0, fmax(-1.0, arg));
+        const double ph = acos(arg) / 3;
+        for (int k = 0; k < 3; ++k) out[n++] = 2 * r * cos(ph - 2 * M_PI * k / 3) - a / 3;
+    }
+    for (int k = 0; k < n; ++k)
+        for (int itn = 0; itn < 3; ++itn) {
+            const double t = out[k], f = ((c[0] * t + c[1]) * t + c[2]) * t + c[3], fp = (3 * c[0] * t + 2 * c[1]) * t + c[2];
+            if (fp != 0) out[k] = t - f / fp;
+        }
+    return n;
+}
+
+// one workgroup per mission: max over (agent, dim, segment) of the per-segment scale, then rescale
+__global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
+    const int mission = blockIdx.x, tid = threadIdx.x, M = s.M, N = s.N, oq = 6 * M, n = 5;
+    if (s.status[mission] != 0) return;
+    __shared__ double red[8];
+    double* T = s.T + (size_t)mission * (M + 1);
+    double* coef = s.coef + (size_t)mission * N * 3 * oq;
+    double ts = 1;
+    if (s.p.time_scale) {
+        for (int it = tid; it < N * 3 * M; it += blockDim.x) {
+            const int qi = it / (3 * M), k = (it / M) % 3, m = it % M;
+            const double* cf = coef + ((size_t)qi * 3 + k) * oq + 6 * m;
+            double cd[4][6];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 6; ++j) cd[i][n - j] = (i <= j) ? coef_derivative(i, j) * cf[n - j] : 0.0;
+            const double dt = T[m + 1] - T[m];
+            {  // scale_to_max_vel :756-794
+                double tsx[8];
+                int nt = real_roots(cd[2], 3, tsx);
+                tsx[nt++] = 0, tsx[nt++] = dt;
+                double vel_max = 0, t_max = 0;
+                for (int a = 0; a < nt; ++a) {
+                    const double t = tsx[a];
+                    if (t < 0 || t > dt) continue;
+                    double vel = 0;
+                    for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(t, n - 1 - i);
+                    vel = fabs(vel);
+                    if (vel_max < vel) vel_max = vel, t_max = t;
+                }
+                double sc = 1;
+                const double lim = s.max_vel[((size_t)mission * N + qi) * 3 + k];
+                while (vel_max > lim && sc < 1e6) {
+                    sc *= 1.1;
+                    double vel = 0;
+                    for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(1 / sc, n - i) * pow(t_max, n - 1 - i);
+                    vel_max = fabs(vel);
+                }
+                if (ts < sc) ts = sc;
+            }
+            {  // scale_to_max_acc :797-847
+                const double a = cd[3][0], b = cd[3][1], cc = cd[3][2], D = b * b - 4 * a * cc;
+                double tsx[4] = {0, dt, 0, 0};
+                int nt = 2;
+                if (D >= 0 && a != 0) {
+                    tsx[nt++] = (-b + sqrt(D)) / (2 * a);
+                    tsx[nt++] = (-b - sqrt(D)) / (2 * a);
+                } else if (a == 0 && b != 0)
+                    tsx[nt++] = -cc / b;
+                double acc_max = 0, t_max = 0;
+                for (int e = 0; e < nt; ++e) {
+                    const double t = tsx[e];
+                    if (t < 0 || t > dt) continue;
+                    double acc = 0;
+                    for (int i = 0; i < 4; ++i) acc += cd[2][i] * pow(t, 3 - i);
+                    acc = fabs(acc);
+                    if (acc_max < acc) acc_max = acc, t_max = t;
+                }
+                double sc = 1;
+                const double lim = s.max_acc[((size_t)mission * N + qi) * 3 + k];
+                while (acc_max > lim && sc < 1e6) {
+                    sc *= 1.1;
+                    double acc = 0;
+                    for (int i = 0; i < 4; ++i) acc += cd[2][i] * pow(1 / sc, n - i) * pow(t_max, 3 - i);
+                    acc_max = fabs(acc);
+                }
+                if (ts < sc) ts = sc;
+            }
+        }
+        // block max
+        for (int o = 32; o > 0; o >>= 1) ts = fmax(ts, __shfl_xor(ts, o));
+        if ((tid & 63) == 0) red[tid >> 6] = ts;
+        __syncthreads();
+        ts = red[0];
+        for (int i = 1; i < (int)blockDim.x / 64; ++i) ts = fmax(ts, red[i]);
+        __syncthreads();
+    }
+    if (tid == 0) s.scalars[(size_t)mission * SC_N + SC_TIME_SCALE] = ts;
+    if (ts != 1) {  // :236-265
+        for (int it = tid; it < N * 3 * oq; it += blockDim.x) {
+            const int i = it % 6;
+            coef[it] = pow(1.0 / ts, n - i) * coef[it];
+        }
+        for (int it = tid; it < N * s.max_boxes; it += blockDim.x) {
+            const int qi = it / s.max_boxes, b = it % s.max_boxes;
+            if (b < s.sfc_count[(size_t)mission * N + qi]) s.sfc_time[((size_t)mission * N + qi) * s.max_boxes + b] *= ts;
+        }
+        for (int m = tid; m < M; m += blockDim.x) s.rsfc_time[(size_t)mission * M + m] *= ts;
+        __syncthreads();
+        for (int m = tid; m <= M; m += blockDim.x) T[m] *= ts;
+    }
+}
+
+}  // namespace
+
+size_t planner_workspace_bytes(int N, int M, int batch_size_eff) {
+    return (ws_doubles(N, M, batch_size_eff) * sizeof(double) + 255) & ~size_t(255);
+}
+
+void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st) {
+    const int N = s.N, M = s.M;
+    // setBatch (rbp_planner.hpp:849-872)
+    int bs = s.p.sequential ? s.p.batch_size : N;
+    if (bs <= 0) bs = 1;
+    if (bs > N) bs = N;
+    const int bmax = (N + bs - 1) / bs;
+    int biter = s.p.sequential ? s.p.batch_iter : 1;
+    if (s.p.sequential && (biter < 0 || biter > bmax)) biter = bmax;
+    const size_t total = (size_t)s.K * N * 3 * 6 * M;
+    const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(dummy_kernel, dim3(g), dim3(256), 0, st, s);
+    if (biter > 0) {
+        if (bs > QP_MAX_NB) {
+            // nk > 72 needs the tiled multi-workgroup factorisation (joint mode with N > 8): not in this round.
+            // Fail loudly: every mission gets RBP_ERR_BAD_ARGUMENT.
+            std::vector<int> bad(s.K, (int)RBP_ERR_BAD_ARGUMENT);
+            hipMemcpyAsync(s.status, bad.data(), sizeof(int) * s.K, hipMemcpyHostToDevice, st);
+            hipStreamSynchronize(st);
+            return;
+        }
+        const int nk = 9 * bs, ld = nk + 1;
+        const size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 8) + 16;
+        hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int iter = 0; iter < s.p.iteration; ++iter)
+            for (int l = 0; l < biter; ++l)
+                hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
+                                   ws_bytes_per_mission / sizeof(double), l, bs, (int)(l == 0));
+    }
+    const size_t tot2 = (size_t)s.K * N * 3 * M;
+    hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(timescale_kernel, dim3(s.K), dim3(256), 0, st, s);
+}

@@ -1,0 +1,63 @@
+// rbp_dev.h — device-side layout of one session (K missions with common N, M) and kernel entry points.
+//
+// HBM layout (all arrays mission-major, SoA inside a mission; sizes for the headline N=64, M=36):
+//   dist      [K] float grids, x-major / z-fastest (0.94 MB each)        — read by the SFC kernel
+//   init_traj [K][N][M+1][3] f32 (28 KB)  T [K][M+1] f64
+//   start/goal[K][N][9] f64   radius [K][N]   max_vel/max_acc [K][N][3]
+//   sfc_count [K][N] i32  sfc_box [K][N][MB][6] f64  sfc_time [K][N][MB] f64
+//   rsfc_normal [K][N(N-1)/2][M][3] f32 (871 KB)   rsfc_time [K][M] f64
+//   ctrl / coef [K][N][3][6M] f64 (332 KB each)
+//   QP workspace per mission (see qp.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rbp.h"
+
+#define SP_EPSILON 1e-9        /* reference: swarm_planner/include/sp_const.hpp:3 */
+#define SP_EPSILON_FLOAT 1e-6  /* sp_const.hpp:4 */
+
+struct DevWorld {
+    int dim[3];
+    int key_min[3];
+    double res;
+    const float* dist;  // device
+};
+
+struct DevParam {
+    double world_min[3], world_max[3];
+    double box_xy_res, box_z_res, downwash;
+    int sequential, batch_size, batch_iter, iteration, time_scale;
+};
+
+// per-session pointers handed to kernels by value
+struct DevSession {
+    int K, N, M, max_boxes, npair;
+    DevParam p;
+    const DevWorld* worlds;   // [K]
+    const float* init_traj;   // [K][N][M+1][3]
+    double* T;                // [K][M+1]
+    const double* start;      // [K][N][9]
+    const double* goal;       // [K][N][9]
+    const double* radius;     // [K][N]
+    const double* max_vel;    // [K][N][3]
+    const double* max_acc;    // [K][N][3]
+    int* sfc_count;           // [K][N]
+    double* sfc_box;          // [K][N][MB][6]
+    double* sfc_time;         // [K][N][MB]
+    float* rsfc_normal;       // [K][npair][M][3]
+    double* rsfc_time;        // [K][M]
+    double* ctrl;             // [K][N][3][6M]
+    double* coef;             // [K][N][3][6M]
+    int* status;              // [K] first error per mission (0 ok)
+    double* scalars;          // [K][8]: time_scale, total_cost, ipm_iters, qp_solved, polished, ...
+    unsigned long long* counters;  // [K][4]: sfc samples, ...
+};
+
+enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6, SC_N = 8 };
+enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
+
+// launchers (defined in the .hip files)
+void launch_corridor(const DevSession& s, hipStream_t st);
+void launch_planner(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
+size_t planner_workspace_bytes(int N, int M, int batch_size_eff);

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's two stage classes, on top of the C ABI (lib/librbp_hip.so).
+
+    Corridor(world, mission, param).update(log, plan)      <-> SwarmPlanning::Corridor::update    rbp_corridor.hpp:13-26
+    RBPPlanner(mission, param).update(log, plan)           <-> SwarmPlanning::RBPPlanner::update  rbp_planner.hpp:21-84
+
+Same argument meaning and error behaviour: `update` returns True/False and mutates the PlanResult in place;
+`last_error` carries what the reference would have sent to ROS_ERROR.  `Session` is the device-resident batched
+form bench.py times.  The HIP library is mandatory: nothing here falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+from . import _abi as A
+from .types import Mission, Param, PlanResult, World
+
+_lib = None
+
+ERROR_TEXT = {
+    A.RBP_ERR_OBSTACLE_IN_INIT_TRAJ: "Corridor: Invalid initial trajectory. Obstacle invades initial trajectory.",
+    A.RBP_ERR_UNEQUAL_TRAJ_LEN: "Corridor: size of initial trajectories must be equal",
+    A.RBP_ERR_INIT_TRAJ_COLLIDE: "Corridor: initial trajectories are collided with each other",
+    A.RBP_ERR_SFC_OVERFLOW: "Corridor: more SFC boxes than plan.max_boxes",
+    A.RBP_ERR_QP_FAILED: "RBPPlanner: Failed to optimize QP",
+    A.RBP_ERR_UNSUPPORTED_DEGREE: "RBPPlanner: n should be 5",
+    A.RBP_ERR_BAD_ARGUMENT: "bad argument",
+    A.RBP_ERR_NO_DEVICE: "no HIP device (the RBP path has no CPU fallback)",
+    A.RBP_ERR_HIP: "HIP runtime error",
+}
+
+
+class RbpLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load lib/librbp_hip.so; fails loudly if it was not built."""
+    global _lib
+    if _lib is None:
+        path = os.path.join(A.LIB_DIR, "librbp_hip.so")
+        if not os.path.exists(path):
+            raise RbpLibraryMissing(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(path)
+        P = C.POINTER
+        L.rbp_version.restype = C.c_char_p
+        L.rbp_last_error.restype = C.c_char_p
+        L.rbp_device_count.restype = C.c_int
+        L.rbp_param_defaults.argtypes = [P(A.rbp_param)]
+        L.rbp_param_defaults.restype = None
+        L.rbp_corridor_update.argtypes = [P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_planner_update.argtypes = [P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_session_create.argtypes = [P(C.c_void_p), C.c_int, C.c_int, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param),
+                                         P(A.rbp_plan)]
+        L.rbp_session_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rbp_session_download.argtypes = [C.c_void_p, P(A.rbp_plan), A.c_int32_p, C.c_void_p]
+        L.rbp_session_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.rbp_session_counters.argtypes = [C.c_void_p, P(A.rbp_counters), C.c_void_p]
+        L.rbp_session_destroy.argtypes = [C.c_void_p]
+        L.rbp_session_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "rbp_param_defaults", "rbp_corridor_update", "rbp_planner_update", "rbp_session_create", "rbp_session_run",
+    "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_version",
+    "rbp_last_error", "rbp_device_count",
+]
+
+
+def last_error():
+    return lib().rbp_last_error().decode()
+
+
+class Corridor:
+    """rbp_corridor.hpp:11-26"""
+
+    def __init__(self, world: World, mission: Mission, param: Param):
+        self.world, self.mission, self.param = world, mission, param
+        self.last_error = ""
+        self.rc = 0
+
+    def update(self, log: bool, plan: PlanResult) -> bool:
+        w, m, p, pl = self.world.c_struct(), self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
+        self.rc = lib().rbp_corridor_update(C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
+        self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
+        return self.rc == 0
+
+
+class RBPPlanner:
+    """rbp_planner.hpp:19-84"""
+
+    def __init__(self, mission: Mission, param: Param):
+        self.mission, self.param = mission, param
+        self.last_error = ""
+        self.rc = 0
+
+    def update(self, log: bool, plan: PlanResult) -> bool:
+        m, p, pl = self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
+        self.rc = lib().rbp_planner_update(C.byref(m), C.byref(p), C.byref(pl))
+        plan.sync_from(pl)
+        self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
+        return self.rc == 0
+
+
+class Session:
+    """K independent missions resident in HBM (e.g. the 50-map sweep of swarm_traj_planner_rbp_test_all.cpp:49-103)."""
+
+    def __init__(self, worlds, missions, param: Param, plans, device=0):
+        K = len(plans)
+        assert len(worlds) == K and len(missions) == K
+        self.K, self.plans, self.param = K, plans, param
+        self._keep = (worlds, missions)
+        self._w = (A.rbp_world * K)(*[w.c_struct() for w in worlds])
+        self._m = (A.rbp_mission * K)(*[m.c_struct() for m in missions])
+        self._p = param.c_struct()
+        self._pl = (A.rbp_plan * K)(*[p.c_struct() for p in plans])
+        self._h = C.c_void_p()
+        rc = lib().rbp_session_create(C.byref(self._h), device, K, self._w, self._m, C.byref(self._p), self._pl)
+        if rc:
+            raise RuntimeError(f"rbp_session_create failed rc={rc}: {ERROR_TEXT.get(rc, '')} | {last_error()}")
+
+    def run(self, stages=A.RBP_STAGE_ALL, stream=None):
+        rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_run rc={rc}: {last_error()}")
+
+    def reset(self, stream=None):
+        rc = lib().rbp_session_reset(self._h, C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_reset rc={rc}: {last_error()}")
+
+    def download(self, stream=None):
+        """copies outputs into the PlanResult objects; returns per-mission status list."""
+        import numpy as np
+        st = np.zeros(self.K, np.int32)
+        lib().rbp_session_download(self._h, self._pl, A.ptr(st, A.c_int32_p), C.c_void_p(stream or 0))
+        for p, c in zip(self.plans, self._pl):
+            p.sync_from(c)
+        return st.tolist()
+
+    def counters(self, stream=None):
+        ct = A.rbp_counters()
+        rc = lib().rbp_session_counters(self._h, C.byref(ct), C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_counters rc={rc}: {last_error()}")
+        return {k: getattr(ct, k) for k, _ in ct._fields_}
+
+    def close(self):
+        if self._h:
+            lib().rbp_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
