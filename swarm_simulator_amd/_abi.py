@@ -1,7 +1,7 @@
 """ctypes mirror of include/rbp.h and include/rbp_host.h (struct layouts only; no compute here).
 
-Both the product libraries (lib/librbp_hip.so, lib/librbp_host.so) and the test oracle
-(oracle/_build/librbp_oracle.so) take these structs, so a test can hand the *same* buffers to both.
+The product libraries (lib/librbp_hip.so, lib/librbp_host.so) take these structs; the test-suite's CPU checker
+uses the same layouts, so a test can hand the *same* buffers to both.
 """
 import ctypes as C
 import os

@@ -176,6 +176,13 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     bool have_corr = true;
     for (int k = 0; k < K; ++k)
         have_corr = have_corr && plans[k].sfc_count && plans[k].sfc_box && plans[k].sfc_time && plans[k].rsfc_normal && plans[k].rsfc_time;
+    // corridor outputs handed in as planner inputs only count if some agent actually has boxes
+    if (have_corr) {
+        bool any = false;
+        for (int k = 0; k < K && !any; ++k)
+            for (int a = 0; a < N && !any; ++a) any = plans[k].sfc_count[a] > 0;
+        have_corr = any;
+    }
     s->have_corridor_inputs = have_corr;
     if (have_corr) {
         s->sfc_count0.resize((size_t)K * N), s->sfc_box0.resize((size_t)K * N * MB * 6), s->sfc_time0.resize((size_t)K * N * MB);

@@ -1,0 +1,77 @@
+"""The C-ABI libraries load and export exactly what include/*.h declares; without a GPU the product fails loudly
+(no CPU fallback).  CPU only — no compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param
+from tests.common import Case
+
+
+def declared_functions(header):
+    text = open(os.path.join(A.REPO_ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_symbol_of_rbp_h():
+    L = planner.lib()
+    names = declared_functions("rbp.h")
+    assert set(names) == set(planner.EXPORTED_SYMBOLS)
+    for n in names:
+        assert getattr(L, n) is not None
+
+
+def test_host_library_exports_every_symbol_of_rbp_host_h():
+    L = host.lib()
+    for n in declared_functions("rbp_host.h"):
+        assert getattr(L, n) is not None
+
+
+def test_param_defaults_match_param_hpp():
+    p = A.rbp_param()
+    planner.lib().rbp_param_defaults(C.byref(p))
+    d = Param()  # param.hpp:44-70
+    assert list(p.world_min) == [d.world_x_min, d.world_y_min, d.world_z_min]
+    assert list(p.world_max) == [d.world_x_max, d.world_y_max, d.world_z_max]
+    assert (p.box_xy_res, p.box_z_res, p.downwash, p.time_step) == (0.1, 0.1, 2.0, 1.0)
+    assert (p.grid_xy_res, p.grid_z_res, p.grid_margin, p.ecbs_w) == (0.3, 0.6, 0.2, 1.3)
+    assert (p.n, p.phi, p.sequential, p.batch_size, p.batch_iter, p.iteration, p.time_scale, p.log) == (5, 3, 0, 4, 0, 1, 1, 0)
+
+
+def test_struct_layout_roundtrip():
+    """the ctypes mirrors and the C structs agree on layout: the oracle (C) reads what Python wrote."""
+    from tests import oracle_lib as O
+    c = Case("c1_4agents_empty_joint")
+    pr = c.inputs()
+    rc, _ = O.corridor_update(c.world, c.mission, c.param, pr)
+    assert rc == 0 and pr.sfc_count.min() >= 1
+
+
+def test_product_has_no_cpu_fallback():
+    if planner.lib().rbp_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    c = Case("c1_4agents_empty_joint")
+    pr = c.inputs()
+    cor = planner.Corridor(c.world, c.mission, c.param)
+    assert cor.update(False, pr) is False
+    assert cor.rc == A.RBP_ERR_NO_DEVICE and "no CPU fallback" in cor.last_error
+    pl = planner.RBPPlanner(c.mission, c.param)
+    assert pl.update(False, c.with_corridor()) is False and pl.rc == A.RBP_ERR_NO_DEVICE
+    assert np.all(pr.sfc_count == 0)  # nothing was computed
+
+
+def test_product_does_not_import_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(A.REPO_ROOT, "swarm_simulator_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(root, f), errors="ignore").read()
+                for needle in ("oracle_lib", "rbp_oracle", "oracle/", "import oracle", "from oracle"):
+                    assert needle not in text, (f, needle)

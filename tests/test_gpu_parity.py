@@ -1,0 +1,167 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden vectors.  Needs an MI355X.
+
+Tolerances (DESIGN.md "Parity"): SFC boxes / times / counts and RSFC normals are integer / float32 procedures
+and must be BIT-EXACT.  The QP answer is floating point: control points within CTRL_TOL metres (sup norm) of the
+oracle's certified optimum, objective within OBJ_RTOL relative, constraints satisfied within FEAS_TOL.
+"""
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param, PlanResult
+from tests import oracle_lib as O
+from tests.common import BIG_CASES, MID_CASES, SMALL_CASES, Case, rsfc_hash
+
+pytestmark = pytest.mark.gpu
+
+CTRL_TOL = 2e-4   # metres; interior-point answer vs polished optimum, compounded over Gauss-Seidel batches
+OBJ_RTOL = 2e-6
+FEAS_TOL = 1e-8
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + MID_CASES + BIG_CASES)
+def test_corridor_bit_exact_vs_golden(name):
+    c = Case(name)
+    pr = c.inputs()
+    cor = planner.Corridor(c.world, c.mission, c.param)
+    assert cor.update(False, pr), cor.last_error
+    g = c.g
+    assert np.array_equal(pr.sfc_count, g["sfc_count"])
+    assert np.array_equal(pr.sfc_box, g["sfc_box"])
+    assert np.array_equal(pr.sfc_time, g["sfc_time0"])
+    assert np.array_equal(pr.rsfc_time, g["rsfc_time0"])
+    assert rsfc_hash(pr) == str(g["rsfc_sha256"])
+
+
+@pytest.mark.parametrize("world,nag", [("map2.bt", 16), ("map17.bt", 32), ("ICRA2020_64agents_presentation.bt", 64),
+                                       ("empty.bt", 8), ("map50.bt", 64)])
+def test_corridor_bit_exact_vs_oracle_on_other_maps(world, nag):
+    p = Param.test_sweep()
+    m = host.load_mission(f"mission_{nag}agents_15.json")
+    w = host.load_world(world, p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    rc, ns = O.corridor_update(w, m, p, ref)
+    assert rc == 0
+    sess = planner.Session([w], [m], p, [gpu])
+    sess.run(A.RBP_STAGE_CORRIDOR)
+    assert sess.download() == [0]
+    assert np.array_equal(ref.sfc_count, gpu.sfc_count) and np.array_equal(ref.sfc_box, gpu.sfc_box)
+    assert np.array_equal(ref.sfc_time, gpu.sfc_time)
+    assert np.array_equal(bits(ref.rsfc_normal), bits(gpu.rsfc_normal))
+    assert int(sess.counters()["sfc_samples"]) == ns   # same getDistance count, same early exits
+    sess.close()
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + MID_CASES + BIG_CASES)
+def test_planner_vs_golden(name):
+    c = Case(name)
+    pr = c.inputs()
+    assert planner.Corridor(c.world, c.mission, c.param).update(False, pr)
+    pl = planner.RBPPlanner(c.mission, c.param)
+    assert pl.update(False, pr), pl.last_error
+    g = c.g
+    assert np.abs(pr.ctrl - g["ctrl"]).max() < CTRL_TOL
+    assert abs(pr.total_cost - float(g["total_cost"])) <= OBJ_RTOL * max(1.0, abs(float(g["total_cost"])))
+    assert pr.time_scale == float(g["time_scale"])
+    assert np.allclose(pr.T, g["T"], rtol=0, atol=1e-12)
+    assert np.abs(pr.coef - g["coef"]).max() < 10 * CTRL_TOL * 3 ** 5  # monomial coefficients amplify by basis * dt^-k
+    assert (pr.x_size, pr.eq_size, pr.ineq_size) == tuple(int(v) for v in g["sizes"])
+    # solver-independent check of the GPU answer against the reference's constraint sets
+    obj, veq, vbox, vrs = O.evaluate_ctrl(c.mission, pr)
+    assert veq < FEAS_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+    assert obj <= float(g["evaluate"][0]) * (1 + OBJ_RTOL) + 1e-9   # no worse than the certified optimum
+
+
+def test_planner_only_call_with_host_corridor():
+    """RBPPlanner::update as a drop-in on a PlanResult whose corridor came from elsewhere (here: the golden)."""
+    c = Case("s8_map5_seq4")
+    pr = c.with_corridor()
+    pl = planner.RBPPlanner(c.mission, c.param)
+    assert pl.update(False, pr), pl.last_error
+    assert np.abs(pr.ctrl - c.g["ctrl"]).max() < CTRL_TOL
+
+
+def test_session_batch_equals_single_missions():
+    """K missions in one session give the same bits as K separate calls (no cross-talk between workgroups)."""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_16agents_15.json")
+    worlds = [host.load_world(f"map{i}.bt", p) for i in (4, 9, 11)]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+    M = max(i.M for i in inits)
+    plans = []
+    for i in inits:
+        pad = M - i.M
+        traj = np.concatenate([i.init_traj, np.repeat(i.init_traj[:, -1:, :], pad, axis=1)], axis=1)
+        T = np.concatenate([i.T, i.T[-1] + np.arange(1, pad + 1)])
+        plans.append(PlanResult(traj, T))
+    singles = [pl.clone_inputs() for pl in plans]
+    sess = planner.Session(worlds, [m] * 3, p, plans)
+    sess.run()
+    assert sess.download() == [0, 0, 0]
+    for w, s in zip(worlds, singles):
+        assert planner.Corridor(w, m, p).update(False, s)
+        assert planner.RBPPlanner(m, p).update(False, s)
+    for a, b in zip(plans, singles):
+        assert np.array_equal(a.sfc_box, b.sfc_box) and np.array_equal(bits(a.rsfc_normal), bits(b.rsfc_normal))
+        assert np.array_equal(a.ctrl, b.ctrl) and np.array_equal(a.coef, b.coef)
+    # re-running after reset reproduces the same bits
+    first = [a.ctrl.copy() for a in plans]
+    sess.reset()
+    sess.run()
+    sess.download()
+    for a, f in zip(plans, first):
+        assert np.array_equal(a.ctrl, f)
+    sess.close()
+
+
+def test_full_size_properties():
+    """C3 (64 agents): size-independent properties of the GPU answer (reference semantics)."""
+    c = Case("c3_64agents_map1")
+    pr = c.inputs()
+    assert planner.Corridor(c.world, c.mission, c.param).update(False, pr)
+    assert planner.RBPPlanner(c.mission, c.param).update(False, pr)
+    M, oq = pr.M, 6 * pr.M
+    ctrl = pr.ctrl
+    # start / goal states (rbp_planner.hpp:408-432) and C2 continuity at every knot (:390-399)
+    assert np.array_equal(ctrl[:, :, 0], c.mission.start[:, :3]) and np.array_equal(ctrl[:, :, oq - 1], c.mission.goal[:, :3])
+    A_eq = O.Aeq_base(c.g["T0"])
+    r = np.einsum("ej,akj->ake", A_eq, ctrl)
+    assert np.abs(r[:, :, 6:]).max() < 1e-9
+    # every control point inside its SFC box, every pair separated by its RSFC half-space
+    obj, veq, vbox, vrs = O.evaluate_ctrl(c.mission, pr)
+    assert vbox < FEAS_TOL and vrs < FEAS_TOL
+    # the reference's own acceptance signal: safety-margin ratio >= 1 (rbp_publisher.hpp:769-798)
+    ratio, dist = host.validate(c.mission, c.param, pr)
+    assert ratio >= 1.0
+    # sampled trajectory stays inside the world box
+    assert ctrl[:, 2].min() >= c.param.world_z_min - FEAS_TOL and ctrl[:, 2].max() <= c.param.world_z_max + FEAS_TOL
+
+
+def test_error_codes_match_the_reference_failure_sites():
+    c = Case("s4_map1_joint")
+    pr = c.inputs()
+    occ = np.argwhere(c.world.dist == 0)[0]
+    pr.init_traj[0, 3] = (np.array(c.world.key_min) + occ + 0.5) * c.world.res
+    cor = planner.Corridor(c.world, c.mission, c.param)
+    assert cor.update(False, pr) is False and cor.rc == A.RBP_ERR_OBSTACLE_IN_INIT_TRAJ   # rbp_corridor.hpp:181-187
+    c2 = Case("c1_4agents_empty_joint")
+    pr2 = c2.inputs()
+    pr2.init_traj[1] = pr2.init_traj[0]
+    cor2 = planner.Corridor(c2.world, c2.mission, c2.param)
+    assert cor2.update(False, pr2) is False and cor2.rc == A.RBP_ERR_INIT_TRAJ_COLLIDE    # :385-388
+    c3 = Case("c1_4agents_empty_joint")
+    c3.param.n = 7
+    pl = planner.RBPPlanner(c3.mission, c3.param)
+    assert pl.update(False, c3.with_corridor()) is False and pl.rc == A.RBP_ERR_UNSUPPORTED_DEGREE  # rbp_planner.hpp:344-346
+    # infeasible QP: shrink an SFC box so that the start point lies outside it  (rbp_planner.hpp:158-161)
+    c4 = Case("s4_map1_joint")
+    pr4 = c4.with_corridor()
+    pr4.sfc_box[0, 0, 3] = pr4.sfc_box[0, 0, 0] + 0.05
+    pl4 = planner.RBPPlanner(c4.mission, c4.param)
+    assert pl4.update(False, pr4) is False and pl4.rc == A.RBP_ERR_QP_FAILED

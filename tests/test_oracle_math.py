@@ -1,0 +1,123 @@
+"""The oracle's building blocks against mathematics and against the reference's only committed artefact
+(swarm_planner/log/coef1..64.csv, packed in tests/golden/ref_log_coef.npz).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+from numpy.polynomial import polynomial as Pn
+
+from tests import oracle_lib as O
+from tests.common import GOLDEN_DIR
+
+
+def bernstein(i, n=5):
+    """coefficients (ascending powers of tau) of B_i^n"""
+    from math import comb
+    p = Pn.polypow([1, -1], n - i)
+    p = Pn.polymul(p, [0] * i + [1])
+    return comb(n, i) * p
+
+
+def test_Q_base_is_jerk_gram_matrix():
+    # rbp_planner.hpp:330-335: Q_base = int_0^1 B'''_i B'''_j dtau  (minimum JERK, phi = 3)
+    Q, _ = O.Q_base()
+    for i in range(6):
+        for j in range(6):
+            d = Pn.polymul(Pn.polyder(bernstein(i), 3), Pn.polyder(bernstein(j), 3))
+            val = Pn.polyval(1.0, Pn.polyint(d))
+            assert abs(val - Q[i, j]) < 1e-9, (i, j, val, Q[i, j])
+    assert np.linalg.matrix_rank(Q) == 3
+
+
+def test_basis_is_bernstein_to_monomial_descending():
+    # rbp_planner.hpp:338-343: row i = B_i in DESCENDING powers
+    _, B = O.Q_base()
+    for i in range(6):
+        assert np.allclose(B[i], bernstein(i)[::-1])
+
+
+def test_ctrl_to_coef_evaluates_the_bernstein_polynomial():
+    rng = np.random.default_rng(1)
+    T = np.array([0.0, 1.0, 2.5, 3.0])
+    ctrl = rng.normal(size=(2, 3, 18))
+    coef = O.ctrl_to_coef(T, ctrl)
+    for m in range(3):
+        h = T[m + 1] - T[m]
+        for t in np.linspace(0, h, 7):
+            tau = t / h
+            want = sum(ctrl[1, 2, 6 * m + i] * Pn.polyval(tau, bernstein(i)) for i in range(6))
+            got = sum(coef[1, 2, 6 * m + i] * t ** (5 - i) for i in range(6))  # descending powers of (t - T_m)
+            assert abs(want - got) < 1e-10
+
+
+def test_Aeq_base_rows_are_state_and_continuity():
+    # rbp_planner.hpp:353-405.  Build a C2 piecewise quintic from knot states, check Aeq c = [start, goal, 0...]
+    rng = np.random.default_rng(2)
+    T = np.array([0.0, 1.0, 1.7, 3.0, 4.0])
+    M = 4
+    states = rng.normal(size=(M + 1, 3))  # p, v, a at every knot
+    c = np.zeros(6 * M)
+    for m in range(M):
+        h = T[m + 1] - T[m]
+        p0, v0, a0 = states[m]
+        p1, v1, a1 = states[m + 1]
+        c[6 * m + 0] = p0
+        c[6 * m + 1] = p0 + h * v0 / 5
+        c[6 * m + 2] = p0 + 2 * h * v0 / 5 + h * h * a0 / 20
+        c[6 * m + 5] = p1
+        c[6 * m + 4] = p1 - h * v1 / 5
+        c[6 * m + 3] = p1 - 2 * h * v1 / 5 + h * h * a1 / 20
+    A = O.Aeq_base(T)
+    r = A @ c
+    assert A.shape == (3 * (M + 1), 6 * M)
+    assert np.allclose(r[0:3], states[0]) and np.allclose(r[3:6], states[M])
+    assert np.allclose(r[6:], 0, atol=1e-12)
+
+
+def test_build_dummy_layout():
+    traj = np.arange(2 * 4 * 3, dtype=np.float32).reshape(2, 4, 3)
+    d = O.build_dummy(traj)  # [N][3][6M]
+    assert d.shape == (2, 3, 18)
+    for m in range(3):
+        assert np.all(d[1, :, 6 * m:6 * m + 3] == traj[1, m][:, None])
+        assert np.all(d[1, :, 6 * m + 3:6 * m + 6] == traj[1, m + 1][:, None])
+
+
+@pytest.mark.parametrize("pi0,pi1,pj0,pj1,expect", [
+    ((0, 0, 1), (0, 0, 1), (1, 0, 1), (1, 0, 1), (1, 0, 0)),            # a == b
+    ((0, 0, 1), (0.5, 0, 1), (2, 0, 1), (1.5, 0, 1), (1, 0, 0)),        # closing head-on, endpoint b closest
+    ((0, 0, 1), (0, 0, 1), (1, -1, 1), (1, 1, 1), (1, 0, 0)),           # passes by: foot of the perpendicular
+    ((0, 0, 1), (0, 0, 1), (0, 0, 2), (0, 0, 2), (0, 0, 0.5)),          # vertical: downwash applied twice
+])
+def test_rsfc_normal_cases(pi0, pi1, pj0, pj1, expect):
+    rc, n = O.rsfc_normal(pi0, pi1, pj0, pj1, 2.0)
+    assert rc == 0
+    assert np.allclose(n, expect, atol=1e-6)
+
+
+def test_rsfc_normal_zero_length_is_an_error():
+    rc, _ = O.rsfc_normal((0, 0, 1), (1, 0, 1), (1, 0, 1), (0, 0, 1), 2.0)  # swap through the origin
+    assert rc == 1
+
+
+def test_reference_log_is_consistent_with_restated_matrices():
+    """the committed run (64 agents, 36 unit segments) must satisfy OUR Aeq_base / Q_base / basis."""
+    g = np.load(os.path.join(GOLDEN_DIR, "ref_log_coef.npz"))
+    dur, coef = g["duration"], g["coef"]  # [64][36], [64][36][3][8 ascending]
+    assert coef.shape == (64, 36, 3, 8) and np.all(dur == 1.0)
+    Q, B = O.Q_base()
+    Binv = np.linalg.inv(B.T)  # coef_desc = B' c  (dt = 1)  ->  c = B'^-1 coef_desc
+    desc = coef[..., 5::-1]    # descending powers, degree 5
+    ctrl = np.einsum("ij,amkj->amki", Binv, desc)  # [64][36][3][6]
+    A = O.Aeq_base(np.arange(37.0))
+    cost = 0.0
+    worst = 0.0
+    for a in range(64):
+        for k in range(3):
+            c = ctrl[a, :, k, :].reshape(-1)
+            r = A @ c
+            worst = max(worst, np.abs(r[6:]).max(), np.abs(r[1:3]).max(), np.abs(r[4:6]).max())
+            cost += sum(c[6 * m:6 * m + 6] @ Q @ c[6 * m:6 * m + 6] for m in range(36))
+    assert worst < 1e-4          # print precision of the CSV (6 significant digits)
+    assert abs(cost - 42.15) < 0.02
+    assert ctrl[:, :, 2, :].min() > 0.3 - 1e-5  # world_z_min = 0.3 floor is respected
