@@ -152,6 +152,9 @@ typedef struct rbp_counters {
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 
+/* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 24 (layout: kernels/rbp_dev.h SC_*) */
+int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
+
 /* library/version/diagnostics */
 const char* rbp_version(void);
 const char* rbp_last_error(void);

@@ -790,6 +790,14 @@ static int qp_solve(const qp_t* q, const double* x0, const oracle_qp_options* op
             rc = RBP_OK;
             break;
         }
+        /* rows inconsistent at rounding level (no interior AND infeasible by ~1e-9, see qp_polish): the regularised
+         * iteration settles on the least-violation point with pres stuck.  Accept it once complementarity and
+         * stationarity are converged and the violation is below CPLEX's default feasibility tolerance 1e-6. */
+        if (pres < 1e-6 && dres < opt->tol_feas && mu < 1e-3 * opt->tol_gap) {
+            rc = RBP_OK;
+            if (rep) rep->n_loose++;
+            break;
+        }
         /* dual proximal regularisation of the inequality rows (Friedlander-Orban):  G dx + ds - dreg dz = -rg.
          * It vanishes at a fixed point (dz = 0) but caps the barrier weights at 1/dreg, which keeps the Newton
          * systems well posed when the feasible set has NO interior -- common here: SFC faces and r_i + r_j = 0.3
@@ -914,129 +922,201 @@ static int qp_solve(const qp_t* q, const double* x0, const oracle_qp_options* op
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Active-set polish ("crossover"): the interior-point iterate identifies the active rows; the optimum is then
- * the solution of the equality-constrained QP   min x'Qx  s.t. Ax = b, G_a x = h_a   which is solved directly
- * (block elimination on top of the w = 0 KKT factorisation, Schur complement over the active rows, delta-
- * regularised with iterative refinement) and ACCEPTED ONLY IF it satisfies every KKT condition of the full QP:
- * multipliers >= 0 and all inactive rows feasible.  This removes the O(sqrt(mu)) bias an interior-point answer
- * keeps in the weakly curved directions of this problem (reduced-Hessian condition number ~1e9).
- * returns 0 if the polished point was accepted (x, y, z, s overwritten).
+ * Active-set polish ("crossover").  The interior-point iterate identifies a candidate set C of rows that may be
+ * active (small slack or dominant multiplier).  The optimum of the QP is then obtained EXACTLY from the dual QP
+ * restricted to C,
+ *        min_z  1/2 z' S z - d' z ,  z >= 0 ,      S = G_C K0^{-1} G_C' ,  d = G_C x0 - h_C ,
+ * (K0 = KKT matrix of the equality-constrained problem, x0 = its solution), solved by the Lawson-Hanson
+ * active-set method: finite, monotone, and indifferent to linearly dependent rows -- which are the rule here,
+ * SFC faces and r_i + r_j sharing one 0.1 m lattice.  x = x0 - V z.  Rows outside C that come out violated are
+ * added to C and the iteration continues.  The result is ACCEPTED ONLY IF it satisfies every KKT condition of the
+ * full QP.  This removes the O(sqrt(mu)) bias an interior-point answer keeps in the weakly curved directions of
+ * this problem (reduced-Hessian condition number ~1e9).  returns 0 if accepted (x, y, z, s overwritten).
  * ---------------------------------------------------------------------------------------------- */
 static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, double* z, double* s, double* flops,
                      int verbose) {
-    const int nx = q->nx, ne = q->ne, nc = q->nc, cap = 2048;
-    int* act = (int*)malloc(sizeof(int) * cap);
-    char* is_act = (char*)calloc(nc, 1);
-    int na = 0;
+    const int nx = q->nx, ne = q->ne, nc = q->nc, cap = 1024;
+    int* cand = (int*)malloc(sizeof(int) * cap);
+    char* in_c = (char*)calloc(nc, 1);
+    int ncand = 0;
     for (int c = 0; c < nc; ++c)
-        if (z[c] > s[c] && na < cap) act[na++] = c, is_act[c] = 1;
+        if ((z[c] > s[c] || s[c] < 1e-6) && ncand < cap) cand[ncand++] = c, in_c[c] = 1;
     double* w0 = (double*)calloc(nc, sizeof(double));
     kkt_t K;
     kkt_init(&K, q, linear_solver);
     int rc = 1;
-    double* V = (double*)malloc(sizeof(double) * (size_t)cap * nx);  /* x-part of K0^{-1}[g_a;0], one row per active */
+    double* V = (double*)malloc(sizeof(double) * (size_t)cap * nx);  /* x-part of K0^{-1}[g_c;0], one row per candidate */
     double* Yv = (double*)malloc(sizeof(double) * (size_t)cap * ne); /* y-part */
     double* S = (double*)malloc(sizeof(double) * (size_t)cap * cap);
+    double* Sp = (double*)malloc(sizeof(double) * (size_t)cap * cap);
     double* x0 = (double*)malloc(sizeof(double) * nx), *xn = (double*)malloc(sizeof(double) * nx);
     double* y0 = (double*)malloc(sizeof(double) * ne), *yn = (double*)malloc(sizeof(double) * ne);
     double* r1 = (double*)calloc(nx, sizeof(double)), *r2 = (double*)calloc(ne, sizeof(double));
-    double* za = (double*)calloc(cap, sizeof(double)), *res = (double*)malloc(sizeof(double) * cap);
+    double* zc = (double*)calloc(cap, sizeof(double)), *d = (double*)malloc(sizeof(double) * cap);
+    double* yv = (double*)malloc(sizeof(double) * cap), *wv = (double*)malloc(sizeof(double) * cap);
+    int* P = (int*)malloc(sizeof(int) * cap);
+    char* in_p = (char*)calloc(cap, 1);
     double* gx = (double*)malloc(sizeof(double) * nc);
-    int nV = 0; /* V rows computed so far (for act[0..nV-1]) */
+    int nV = 0, nP = 0, lh_iters = 0;
     if (kkt_factor(&K, w0)) goto out;
     kkt_solve(&K, r1, q->beq, x0, y0); /* K0 [x0;y0] = [0;b] */
-    const double delta = 1e-9;
-    for (int pass = 0; pass < 30; ++pass) {
-        for (; nV < na; ++nV) { /* K0 [V_a; Y_a] = [g_a; 0] for the new rows */
-            int c = act[nV];
+    op_Gx(q, x0, gx);
+    for (int outer = 0; outer < 20; ++outer) {
+        for (; nV < ncand; ++nV) { /* new candidates: K0 [V;Y] = [g;0], extend S and d */
+            int c = cand[nV];
             memset(r1, 0, sizeof(double) * nx);
             for (int e = 0; e < q->gnnz[c]; ++e) r1[q->gcol[6 * c + e]] = q->gval[6 * c + e];
             kkt_solve(&K, r1, r2, V + (size_t)nV * nx, Yv + (size_t)nV * ne);
-        }
-        for (int a = 0; a < na; ++a)
-            for (int b = 0; b <= a; ++b) {
-                int c = act[a];
-                double sum = 0;
+            d[nV] = gx[c] - q->h[c];
+            zc[nV] = 0, in_p[nV] = 0;
+            for (int b = 0; b <= nV; ++b) {
+                int cb = cand[b];
+                double sum = 0, sum2 = 0;
                 for (int e = 0; e < q->gnnz[c]; ++e) sum += q->gval[6 * c + e] * V[(size_t)b * nx + q->gcol[6 * c + e]];
-                S[(size_t)a * na + b] = sum;
+                for (int e = 0; e < q->gnnz[cb]; ++e) sum2 += q->gval[6 * cb + e] * V[(size_t)nV * nx + q->gcol[6 * cb + e]];
+                S[(size_t)nV * cap + b] = S[(size_t)b * cap + nV] = 0.5 * (sum + sum2);
             }
-        for (int a = 0; a < na; ++a) S[(size_t)a * na + a] += delta;
-        if (na && chol_lower(na, S, na)) goto out;
-        *flops += (double)na * na * na / 3 + 2.0 * na * na * 6;
-        memcpy(xn, x0, sizeof(double) * nx);
-        memset(za, 0, sizeof(double) * na);
-        double rmax = 0;
-        for (int round = 0; round < 6; ++round) { /* refinement on  G_a x(za) = h_a  with x(za) = x0 - V za */
-            rmax = 0;
-            for (int a = 0; a < na; ++a) {
-                int c = act[a];
-                double sum = 0;
-                for (int e = 0; e < q->gnnz[c]; ++e) sum += q->gval[6 * c + e] * xn[q->gcol[6 * c + e]];
-                res[a] = sum - q->h[c];
-                if (fabs(res[a]) > rmax) rmax = fabs(res[a]);
+        }
+        /* Lawson-Hanson on the candidate rows */
+        double dscale = 1e-300;
+        for (int a = 0; a < ncand; ++a) dscale = fmax(dscale, fabs(d[a]));
+        const double wtol = 1e-12 * fmax(1.0, dscale);
+        for (int itn = 0; itn < 4 * ncand + 10; ++itn, ++lh_iters) {
+            int jbest = -1;
+            double wbest = wtol;
+            for (int a = 0; a < ncand; ++a) {
+                double sum = d[a];
+                for (int b = 0; b < nP; ++b) sum -= S[(size_t)a * cap + P[b]] * zc[P[b]];
+                wv[a] = sum; /* residual violation of row a */
+                if (!in_p[a] && sum > wbest) wbest = sum, jbest = a;
             }
-            if (rmax < 1e-13) break;
-            if (na) {
-                trsm_lower(na, 1, S, na, res, 1);
-                trsm_lower_t(na, 1, S, na, res, 1);
+            if (jbest < 0) break;
+            P[nP++] = jbest, in_p[jbest] = 1;
+            for (int inner = 0; inner < 2 * cap; ++inner) {
+                double tr = 0;
+                for (int a = 0; a < nP; ++a) {
+                    for (int b = 0; b <= a; ++b) Sp[(size_t)a * nP + b] = S[(size_t)P[a] * cap + P[b]];
+                    tr += Sp[(size_t)a * nP + a];
+                }
+                for (int a = 0; a < nP; ++a) Sp[(size_t)a * nP + a] += 1e-14 * tr / nP + 1e-300;
+                for (int a = 0; a < nP; ++a) yv[a] = d[P[a]];
+                if (chol_lower(nP, Sp, nP)) { /* dependent row slipped in: drop the newcomer */
+                    in_p[P[nP - 1]] = 0, nP--;
+                    break;
+                }
+                trsm_lower(nP, 1, Sp, nP, yv, 1);
+                trsm_lower_t(nP, 1, Sp, nP, yv, 1);
+                *flops += (double)nP * nP * nP / 3;
+                double ymin = 1e300;
+                for (int a = 0; a < nP; ++a) ymin = fmin(ymin, yv[a]);
+                if (ymin > 0) {
+                    for (int a = 0; a < nP; ++a) zc[P[a]] = yv[a];
+                    break;
+                }
+                double alpha = 1e300;
+                for (int a = 0; a < nP; ++a)
+                    if (yv[a] <= 0) alpha = fmin(alpha, zc[P[a]] / (zc[P[a]] - yv[a]));
+                if (!(alpha >= 0)) alpha = 0;
+                int keep = 0;
+                for (int a = 0; a < nP; ++a) {
+                    int ia = P[a];
+                    zc[ia] += alpha * (yv[a] - zc[ia]);
+                    if (yv[a] <= 0 && zc[ia] <= 1e-14 * fmax(1.0, fabs(yv[a]))) {
+                        zc[ia] = 0, in_p[ia] = 0;
+                        continue;
+                    }
+                    P[keep++] = ia;
+                }
+                if (keep == nP) { /* numerical safety: drop the most negative target */
+                    int worst = 0;
+                    for (int a = 1; a < nP; ++a)
+                        if (yv[a] < yv[worst]) worst = a;
+                    zc[P[worst]] = 0, in_p[P[worst]] = 0;
+                    for (int a = worst; a + 1 < nP; ++a) P[a] = P[a + 1];
+                    keep = nP - 1;
+                }
+                nP = keep;
+                if (nP == 0) break;
             }
-            for (int a = 0; a < na; ++a) za[a] += res[a];
+        }
+        /* primal point; iterative refinement of z on the active rows against the ACTUAL residual G_P x - h_P
+         * (S and d were formed from V and x0, which carry the ~1e-9 relative error of solves with K0) */
+        for (int round = 0; round < 5; ++round) {
             memcpy(xn, x0, sizeof(double) * nx);
-            for (int a = 0; a < na; ++a) {
-                const double* v = V + (size_t)a * nx;
-                double zz = za[a];
+            for (int a = 0; a < nP; ++a) {
+                const double* v = V + (size_t)P[a] * nx;
+                double zz = zc[P[a]];
                 for (int i = 0; i < nx; ++i) xn[i] -= zz * v[i];
             }
+            if (nP == 0 || round == 4) break;
+            double rmax = 0;
+            for (int a = 0; a < nP; ++a) {
+                int c = cand[P[a]];
+                double sum = -q->h[c];
+                for (int e = 0; e < q->gnnz[c]; ++e) sum += q->gval[6 * c + e] * xn[q->gcol[6 * c + e]];
+                yv[a] = sum;
+                rmax = fmax(rmax, fabs(sum));
+            }
+            if (rmax < 1e-13) break;
+            double tr = 0;
+            for (int a = 0; a < nP; ++a) {
+                for (int b = 0; b <= a; ++b) Sp[(size_t)a * nP + b] = S[(size_t)P[a] * cap + P[b]];
+                tr += Sp[(size_t)a * nP + a];
+            }
+            for (int a = 0; a < nP; ++a) Sp[(size_t)a * nP + a] += 1e-14 * tr / nP + 1e-300;
+            if (chol_lower(nP, Sp, nP)) break;
+            trsm_lower(nP, 1, Sp, nP, yv, 1);
+            trsm_lower_t(nP, 1, Sp, nP, yv, 1);
+            for (int a = 0; a < nP; ++a) zc[P[a]] += yv[a];
         }
-        /* KKT conditions of the FULL problem */
         op_Gx(q, xn, gx);
-        double zmin = 0, vmax = 0, zmax = 0;
-        int n_add = 0, n_drop = 0;
-        for (int a = 0; a < na; ++a) {
-            if (za[a] < zmin) zmin = za[a];
-            if (za[a] > zmax) zmax = za[a];
+        double vmax = 0, zmin = 0;
+        int n_add = 0;
+        for (int a = 0; a < nP; ++a) zmin = fmin(zmin, zc[P[a]]);
+        for (int c = 0; c < nc; ++c) {
+            double v = gx[c] - q->h[c];
+            if (v > vmax) vmax = v;
+            if (v > 1e-11 && !in_c[c] && ncand < cap) cand[ncand++] = c, in_c[c] = 1, n_add++;
         }
-        for (int c = 0; c < nc; ++c)
-            if (!is_act[c] && gx[c] - q->h[c] > vmax) vmax = gx[c] - q->h[c];
         if (verbose)
-            printf("    polish pass %d: active %d, |G_a x - h_a| %.2e, min multiplier %.3e, max violation %.3e\n", pass, na,
-                   rmax, zmin, vmax);
-        const double ztol = 1e-9 * fmax(1.0, zmax);
-        if (zmin >= -ztol && vmax <= 1e-10 && rmax < 1e-10) {
+            printf("    polish round %d: candidates %d, active %d, LH iterations %d, max violation %.3e, added %d\n", outer,
+                   ncand - n_add, nP, lh_iters, vmax, n_add);
+        if (n_add == 0) {
+            if (vmax > 1e-9 || zmin < -1e-9) break; /* not converged: reject */
             memcpy(yn, y0, sizeof(double) * ne);
-            for (int a = 0; a < na; ++a)
-                for (int e = 0; e < ne; ++e) yn[e] -= za[a] * Yv[(size_t)a * ne + e];
+            for (int a = 0; a < nP; ++a)
+                for (int e = 0; e < ne; ++e) yn[e] -= zc[P[a]] * Yv[(size_t)P[a] * ne + e];
+            /* restore A x = b to rounding level (x0 and the columns of V carry ~1e-13 relative solve error, scaled
+             * by multipliers up to 1e3), then put control points with an ACTIVE SFC bound exactly on the face.
+             * Both matter for the next Gauss-Seidel batch: its rows against these (then frozen) control points sit
+             * on the same 0.1 m lattice, and a 1e-9 inconsistency there makes that batch infeasible by 1e-9. */
+            if (!linear_solver) {
+                op_Ax(q, xn, r2);
+                for (int e = 0; e < ne; ++e) r2[e] -= q->beq[e];
+                solve_AAt(&K, r2);
+                for (int e = 0; e < ne; ++e) r2[e] = -r2[e];
+                op_ATy_add(q, r2, xn);
+                memset(r2, 0, sizeof(double) * ne);
+            }
+            for (int a = 0; a < nP; ++a) {
+                int c = cand[P[a]];
+                if (q->gnnz[c] == 1 && zc[P[a]] > 0) xn[q->gcol[6 * c]] = q->h[c] / q->gval[6 * c];
+            }
+            op_Gx(q, xn, gx);
             memcpy(x, xn, sizeof(double) * nx);
             memcpy(y, yn, sizeof(double) * ne);
             for (int c = 0; c < nc; ++c) z[c] = 0, s[c] = fmax(q->h[c] - gx[c], 0.0);
-            for (int a = 0; a < na; ++a) z[act[a]] = fmax(za[a], 0.0);
+            for (int a = 0; a < nP; ++a) z[cand[P[a]]] = zc[P[a]];
             rc = 0;
             break;
         }
-        /* primal-dual active-set update: drop rows with a negative multiplier, add violated rows */
-        int keep = 0;
-        for (int a = 0; a < na; ++a) {
-            if (za[a] < -ztol) {
-                is_act[act[a]] = 0, n_drop++;
-                continue;
-            }
-            if (keep != a) {
-                act[keep] = act[a];
-                memcpy(V + (size_t)keep * nx, V + (size_t)a * nx, sizeof(double) * nx);
-                memcpy(Yv + (size_t)keep * ne, Yv + (size_t)a * ne, sizeof(double) * ne);
-            }
-            keep++;
-        }
-        na = nV = keep;
-        for (int c = 0; c < nc && na < cap; ++c)
-            if (!is_act[c] && gx[c] - q->h[c] > 1e-10) act[na++] = c, is_act[c] = 1, n_add++;
-        if (n_add == 0 && n_drop == 0) break; /* residual not converging */
+        op_Gx(q, x0, gx); /* d of the new candidates is measured at x0 */
     }
 out:
     *flops += K.flops;
     kkt_free(&K);
-    free(act), free(is_act), free(w0), free(V), free(S), free(x0), free(y0), free(r1), free(r2), free(Yv), free(za),
-        free(res), free(xn), free(yn), free(gx);
+    free(cand), free(in_c), free(w0), free(V), free(Yv), free(S), free(Sp), free(x0), free(xn), free(y0), free(yn), free(r1),
+        free(r2), free(zc), free(d), free(yv), free(wv), free(P), free(in_p), free(gx);
     return rc;
 }
 

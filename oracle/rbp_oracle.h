@@ -44,6 +44,7 @@ typedef struct oracle_qp_report {
     int32_t iters_total;
     int32_t iters_max;
     int32_t n_polished;    /* QPs whose polished solution was accepted */
+    int32_t n_loose;       /* QPs accepted with a primal residual between tol_feas and 1e-6 (inconsistent rows) */
     double kkt_stationarity; /* worst over QPs: || 2Qx + A'y + G'z ||_inf / (1 + ||2Qx||_inf) */
     double kkt_primal_eq;    /* || Ax - b ||_inf */
     double kkt_primal_ineq;  /* max (Gx - h)_+ */

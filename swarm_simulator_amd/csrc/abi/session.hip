@@ -128,6 +128,10 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
         return fail(RBP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     s->arena.size = total;
+    if (hipMemset(s->arena.base, 0, total) != hipSuccess) {
+        rbp_session_destroy(s);
+        return fail(RBP_ERR_HIP, "hipMemset failed");
+    }
     DevSession& d = s->d;
     d.K = K, d.N = N, d.M = M, d.max_boxes = MB, d.npair = npair;
     for (int a = 0; a < 3; ++a) d.p.world_min[a] = param->world_min[a], d.p.world_max[a] = param->world_max[a];
@@ -314,6 +318,16 @@ int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
         out->qp_solves += sc[(size_t)k * SC_N + SC_QP_SOLVED];
         out->qp_constraint_rows += sc[(size_t)k * SC_N + SC_ROWS];
     }
+    return RBP_OK;
+}
+
+int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream) {
+    if (!s || !out || n <= 0 || n > SC_N) return fail(RBP_ERR_BAD_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::vector<double> sc((size_t)s->d.K * SC_N);
+    HIP_TRY(hipMemcpy(sc.data(), s->d.scalars, sizeof(double) * sc.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < s->d.K; ++k) memcpy(out + (size_t)k * n, &sc[(size_t)k * SC_N], sizeof(double) * n);
     return RBP_OK;
 }
 

@@ -20,11 +20,31 @@
 
 #include "rbp_dev.h"
 
-#define QP_THREADS 256
+#define QP_THREADS 512
 #define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
 #define QP_MAX_ITERS 80
 
 namespace {
+
+#ifdef QP_PROFILE
+#define PROF_DECL long long prof_t0 = wall_clock64(), prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i)                                \
+    do {                                       \
+        __syncthreads();                       \
+        long long t_ = wall_clock64();         \
+        prof_acc[i] += t_ - prof_t0;           \
+        prof_t0 = t_;                          \
+    } while (0)
+#define PROF_FLUSH(scal)                                                         \
+    do {                                                                         \
+        if (threadIdx.x == 0)                                                    \
+            for (int i_ = 0; i_ < 12; ++i_) scal[SC_PROF0 + i_] += (double)prof_acc[i_]; \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH(scal)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // dimensions of one batch QP
@@ -54,15 +74,17 @@ struct QpWs {
     double *dx, *dxa, *cvec;        // [nb*3*oq]
     double *rbase, *rhs;            // [(M-1)*nk]
     double *Td, *To;                // [(M-1)][nk*nk], [(M-2)][nk*nk]
+    double *Lf;                     // [(M-1)][4][nk*nk] factor blocks in lane-friendly layouts (wave-register path)
     double *boxlo, *boxhi;          // [nb][M][3]
     double *Lk, *Dk, *Ek;           // [M+1][9]
+    double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
 };
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
-               2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
-               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + 64;
+               2 * (size_t)d.nj * d.nk + 5 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64;
     return n;
 }
 
@@ -84,11 +106,13 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.rhs = p, p += (size_t)dm.nj * dm.nk;
     w.Td = p, p += (size_t)dm.nj * dm.nk * dm.nk;
     w.To = p, p += (size_t)(dm.nj > 1 ? dm.nj - 1 : 1) * dm.nk * dm.nk;
+    w.Lf = p, p += 4 * (size_t)dm.nj * dm.nk * dm.nk;
     w.boxlo = p, p += (size_t)nbmax * d.M * 3;
     w.boxhi = p, p += (size_t)nbmax * d.M * 3;
     w.Lk = p, p += (size_t)(d.M + 1) * 9;
     w.Dk = p, p += (size_t)(d.M + 1) * 9;
     w.Ek = p, p += (size_t)(d.M + 1) * 9;
+    w.segsc = p, p += d.M;
     return w;
 }
 
@@ -124,6 +148,7 @@ __device__ inline double block_reduce(double v, int op /*0 sum,1 max,2 min*/, do
 // ------------------------------------------------------------------------------------------------------------
 __device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
     const int M = d.M;
+    for (int m = threadIdx.x; m < M; m += QP_THREADS) w.segsc[m] = pow(T[m + 1] - T[m], -5.0);
     for (int j = threadIdx.x; j <= M; j += QP_THREADS) {
         double* L = w.Lk + 9 * j;
         for (int e = 0; e < 9; ++e) L[e] = 0;
@@ -413,14 +438,13 @@ __device__ void grad_ctrl(const RowCtx& c) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int oq = d.oq;
-    const double* T = c.S->T + (size_t)c.mission * (d.M + 1);
     for (int it = threadIdx.x; it < d.nb * 3 * oq; it += QP_THREADS) {
         const int a = it / (3 * oq), k = (it / oq) % 3, j6 = it % oq, m = j6 / 6, i = j6 % 6;
         if (j6 < 3 || j6 >= oq - 3) {  // pinned control point: not a variable
             w.cvec[it] = 0;
             continue;
         }
-        const double sc = pow(T[m + 1] - T[m], -5.0);
+        const double sc = w.segsc[m];
         const double* xs = c.ctrl + ((size_t)(d.first + a) * 3 + k) * oq + 6 * m;
         double g = 0;
 #pragma unroll
@@ -471,35 +495,40 @@ __device__ void assemble_blocks(const RowCtx& c) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int nk = d.nk, oq = d.oq, nb = d.nb;
-    const size_t nent = (size_t)d.nj * nk * nk;
-    for (size_t it = threadIdx.x; it < nent; it += QP_THREADS) {
-        const int j = (int)(it / ((size_t)nk * nk)) + 1;
-        const int rr = (int)(it % ((size_t)nk * nk)) / nk, cc = (int)(it % ((size_t)nk * nk)) % nk;
-        const int a = rr / 9, k = (rr / 3) % 3, e = rr % 3;
-        const int b = cc / 9, l = (cc / 3) % 3, f = cc % 3;
-        const double* L = w.Lk + 9 * j;
-        double acc = 0;
+    // work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out
+    const int per_knot = nb * nb * 9;
+    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
+        const int j = it / per_knot + 1, r = it % per_knot;
+        const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
+        double Sv[6];
+#pragma unroll
         for (int p = 0; p < 6; ++p) {
             const int j6 = 6 * (j - 1) + 3 + p;
-            const double te = p < 3 ? L[3 * p + e] : (p - 3 == e ? 1.0 : 0.0);
-            const double tf = p < 3 ? L[3 * p + f] : (p - 3 == f ? 1.0 : 0.0);
-            if (te == 0.0 || tf == 0.0) continue;
-            double s = 0;
+            double sv;
             if (a == b) {
-                s = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
+                sv = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
                 int pr = 0;
                 for (int p1 = 0; p1 < nb; ++p1)
                     for (int q1 = p1 + 1; q1 < nb; ++q1, ++pr)
-                        if (p1 == a || q1 == a) s += sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+                        if (p1 == a || q1 == a) sv += sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
             } else {
                 const int lo = a < b ? a : b, hi = a < b ? b : a;
                 const int pr = lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1);
-                s = -sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+                sv = -sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
             }
-            acc += s * te * tf;
+            Sv[p] = sv;
         }
-        if (a == b && k == l) acc += w.Dk[9 * j + 3 * e + f];
-        w.Td[it] = acc;
+        const double* L = w.Lk + 9 * j;
+        double* out = w.Td + (size_t)(j - 1) * nk * nk + (size_t)(a * 9 + k * 3) * nk + b * 9 + l * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
+                if (e == f) acc += Sv[3 + e];
+                if (a == b && k == l) acc += w.Dk[9 * j + 3 * e + f];
+                out[(size_t)e * nk + f] = acc;
+            }
     }
     if (d.nj > 1) {
         const size_t noff = (size_t)(d.nj - 1) * nk * nk;
@@ -587,13 +616,16 @@ __device__ bool factor_blocks(const QpDims& d, const QpWs& w, double* lA, double
     return true;
 }
 
-// solve T du = rhs in place (rhs in global, one nk-vector per knot); lv = LDS scratch of 2*nk doubles
-__device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double* lv) {
-    const int nk = d.nk, tid = threadIdx.x;
+// solve T du = rhs in place (rhs in global, one nk-vector per knot); lv = LDS scratch of 2*nk doubles.
+// The diagonal factor of each knot is staged into LDS (lA) before the substitution: the substitution is a chain
+// of nk dependent steps and must not pay a global-memory latency per step.
+__device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
+    const int nk = d.nk, ld = d.ld, tid = threadIdx.x;
     double* cur = lv;
     double* prev = lv + nk;
     for (int j = 0; j < d.nj; ++j) {  // forward
         const double* Dg = w.Td + (size_t)j * nk * nk;
+        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
         for (int r = tid; r < nk; r += QP_THREADS) {
             double s = rhs[(size_t)j * nk + r];
             if (j > 0) {
@@ -605,10 +637,10 @@ __device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double
         __syncthreads();
         if (tid < 64) {  // forward substitution with the diagonal factor, wave 0, column oriented
             for (int cidx = 0; cidx < nk; ++cidx) {
-                const double xc = cur[cidx] / Dg[(size_t)cidx * nk + cidx];
+                const double xc = cur[cidx] / lA[cidx * ld + cidx];
                 __builtin_amdgcn_wave_barrier();
                 if (tid == 0) cur[cidx] = xc;
-                for (int r = cidx + 1 + tid; r < nk; r += 64) cur[r] -= Dg[(size_t)r * nk + cidx] * xc;
+                for (int r = cidx + 1 + tid; r < nk; r += 64) cur[r] -= lA[r * ld + cidx] * xc;
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -618,6 +650,7 @@ __device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double
     }
     for (int j = d.nj - 1; j >= 0; --j) {  // backward
         const double* Dg = w.Td + (size_t)j * nk * nk;
+        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
         for (int cidx = tid; cidx < nk; cidx += QP_THREADS) {
             double s = rhs[(size_t)j * nk + cidx];
             if (j + 1 < d.nj) {
@@ -629,10 +662,10 @@ __device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double
         __syncthreads();
         if (tid < 64) {  // back substitution with A' (row oriented on A)
             for (int cidx = nk - 1; cidx >= 0; --cidx) {
-                const double xc = cur[cidx] / Dg[(size_t)cidx * nk + cidx];
+                const double xc = cur[cidx] / lA[cidx * ld + cidx];
                 __builtin_amdgcn_wave_barrier();
                 if (tid == 0) cur[cidx] = xc;
-                for (int k = tid; k < cidx; k += 64) cur[k] -= Dg[(size_t)cidx * nk + k] * xc;
+                for (int k = tid; k < cidx; k += 64) cur[k] -= lA[cidx * ld + k] * xc;
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -640,6 +673,184 @@ __device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double
         for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r], prev[r] = cur[r];
         __syncthreads();
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// wave-register path (nk <= 36, i.e. batches of up to 4 agents): the whole block-tridiagonal Cholesky and the
+// substitutions run in ONE wavefront with matrix rows held in VGPRs (lane r = row r, NK doubles per block) and
+// v_readlane broadcasts instead of LDS traffic: every step of the dependent chains costs a few issue cycles
+// instead of an LDS round trip, and no workgroup barrier is needed inside a knot.
+//   Lf[j][0] = L_jj     stored [k][r] (lane r reads its row,    coalesced)
+//   Lf[j][1] = L_jj     stored [r][k] (lane r reads its column, coalesced)   -> back substitution
+//   Lf[j][2] = L_{j+1,j} stored [k][r] (row r)                               -> forward elimination
+//   Lf[j][3] = L_{j+1,j} stored [r][k] (column r)                            -> backward elimination
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rl(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NK>
+__device__ bool wave_factor(const QpDims& d, const QpWs& w) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < NK;
+    const int rr = act ? r : 0;
+    double a[NK], b[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) b[k] = 0;
+    bool ok = true;
+    for (int j = 0; j < d.nj; ++j) {
+        const double* Tg = w.Td + (size_t)j * NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
+        if (j > 0) {  // a -= b B'  (b = row r of L_{j,j-1})
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                double sum = 0;
+#pragma unroll
+                for (int m = 0; m < NK; ++m) sum += b[m] * rl(b[m], k);
+                a[k] -= sum;
+            }
+        }
+        // right-looking Cholesky: after step c, a[c] holds L[r][c] for lanes r >= c
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const double dcc = rl(a[c], c);
+            if (!(dcc > 0)) ok = false;
+            const double inv = 1.0 / sqrt(dcc);
+            a[c] *= inv;
+#pragma unroll
+            for (int k = c + 1; k < NK; ++k) a[k] -= a[c] * rl(a[c], k);
+        }
+        if (!ok) return false;
+        double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const double v = k <= r ? a[k] : 0.0;
+                L0[k * NK + r] = v;            // [k][r]: row access
+                L0[NK * NK + r * NK + k] = v;  // [r][k]: column access by lane k later
+            }
+        }
+        if (j + 1 < d.nj) {
+            // b <- row r of T_{j+1,j} = blockdiag(E_{j+1}')  (assemble_blocks: rows u_{j+1}, cols u_j), then b <- b L_jj^{-T}
+            const double* E = w.Ek + 9 * (j + 1);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (k % 3) + (rr % 3)] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NK; ++c) {
+                const double xc = b[c] / rl(a[c], c);
+                b[c] = xc;
+#pragma unroll
+                for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
+            }
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    L0[2 * NK * NK + k * NK + r] = b[k];
+                    L0[3 * NK * NK + r * NK + k] = b[k];
+                }
+            }
+        }
+    }
+    return true;
+}
+
+template <int NK>
+__device__ void wave_solve(const QpDims& d, const QpWs& w, double* rhs) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < NK;
+    const int rr = act ? r : 0;
+    double a[NK], b[NK];
+    double prev = 0;
+    for (int j = 0; j < d.nj; ++j) {  // forward: L y = rhs
+        const double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = L0[k * NK + rr];
+        double v = rhs[(size_t)j * NK + rr];
+        if (j > 0) {
+            const double* Lo = w.Lf + (size_t)(j - 1) * 4 * NK * NK + 2 * NK * NK;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) b[k] = Lo[k * NK + rr];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+        }
+        double dg = 1.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
+        const double inv = 1.0 / dg;
+#pragma unroll
+        for (int c = 0; c < NK; ++c) {
+            const double xc = rl(v, c) * rl(inv, c);
+            v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
+        }
+        prev = v;
+        if (act) rhs[(size_t)j * NK + r] = v;
+    }
+    for (int j = d.nj - 1; j >= 0; --j) {  // backward: L' x = y
+        const double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = L0[NK * NK + k * NK + rr];  // a[k] = L[k][r]
+        double v = prev;  // == rhs_j for the last knot; overwritten below otherwise
+        if (j + 1 < d.nj) {
+            v = rhs[(size_t)j * NK + rr];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) b[k] = L0[3 * NK * NK + k * NK + rr];  // b[k] = L_{j+1,j}[k][r]
+#pragma unroll
+            for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+        }
+        double dg = 1.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
+        const double inv = 1.0 / dg;
+#pragma unroll
+        for (int c = NK - 1; c >= 0; --c) {
+            const double xc = rl(v, c) * rl(inv, c);
+            v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
+        }
+        prev = v;
+        if (act) rhs[(size_t)j * NK + r] = v;
+    }
+}
+
+__device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
+    if (d.nk <= 36) {
+        if (threadIdx.x == 0) *flag = 0;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            bool ok = true;
+            switch (d.nk) {
+                case 9: ok = wave_factor<9>(d, w); break;
+                case 18: ok = wave_factor<18>(d, w); break;
+                case 27: ok = wave_factor<27>(d, w); break;
+                default: ok = wave_factor<36>(d, w); break;
+            }
+            if (!ok && threadIdx.x == 0) *flag = 1;
+        }
+        __threadfence_block();
+        __syncthreads();
+        return *flag == 0;
+    }
+    return factor_blocks(d, w, lA, lB, lC, flag);
+}
+
+__device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
+    if (d.nk <= 36) {
+        if (threadIdx.x < 64) {
+            switch (d.nk) {
+                case 9: wave_solve<9>(d, w, rhs); break;
+                case 18: wave_solve<18>(d, w, rhs); break;
+                case 27: wave_solve<27>(d, w, rhs); break;
+                default: wave_solve<36>(d, w, rhs); break;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        return;
+    }
+    solve_blocks(d, w, rhs, lv, lA);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -689,8 +900,8 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     double* lB = lA + (size_t)d.nk * d.ld;
     double* lC = lB + (size_t)d.nk * d.ld;
     double* lv = lC + (size_t)d.nk * d.ld;  // 2*nk
-    double* red = lv + 2 * d.nk;            // 8
-    int* flag = (int*)(red + 8);
+    double* red = lv + 2 * d.nk;            // 16
+    int* flag = (int*)(red + 16);
 
     mission_constants(d, T, const_cast<QpWs&>(w));
 
@@ -724,6 +935,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     __threadfence_block();
     __syncthreads();
 
+    PROF_DECL;
     PassIO io;
     io.mu0 = 1e-2, io.s_floor = 1e-2, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
     // presolve: constant rows (pinned control points) must hold within 1e-6 (CPLEX default feasibility tolerance)
@@ -746,7 +958,9 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         it_count = iter;
         // ---- sweep 1: weights, accumulators, residual norms
         io.sum0 = 0, io.vmax = 0;
+        PROF(0);
         row_pass<PASS_BUILD>(c, io);
+        PROF(1);
         const double gap = block_reduce(io.sum0, 0, red);
         const double pres = block_reduce(io.vmax, 1, red);
         __threadfence_block();
@@ -767,12 +981,21 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
             ok = true;
             break;
         }
+        // rows inconsistent at rounding level (no interior and infeasible by ~1e-9): the regularised iteration settles
+        // on the least-violation point with pres stuck; accept below CPLEX's default feasibility tolerance 1e-6.
+        if (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) {
+            ok = true;
+            break;
+        }
+        PROF(2);
         // ---- Newton matrix and factorisation
         assemble_blocks(c);
+        PROF(3);
         __threadfence_block();
         __syncthreads();
-        if (!factor_blocks(d, w, lA, lB, lC, flag)) break;
+        if (!factor_dispatch(d, w, lA, lB, lC, flag)) break;
         flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
+        PROF(4);
         // ---- predictor
         gtv_ctrl(c);  // cvec = G'v (v from BUILD)
         __threadfence_block();
@@ -783,12 +1006,16 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
         __threadfence_block();
         __syncthreads();
-        solve_blocks(d, w, w.rhs, lv);
+        PROF(5);
+        solve_dispatch(d, w, w.rhs, lv, lA);
+        PROF(6);
         apply_F(d, w, w.rhs, w.dxa);
         __threadfence_block();
         __syncthreads();
         io.sum0 = io.sum1 = io.sum2 = 0, io.vmin = 1.0;
+        PROF(5);
         row_pass<PASS_AFF>(c, io);
+        PROF(7);
         const double a_aff = block_reduce(io.vmin, 2, red);
         const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
         const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows_free;
@@ -799,6 +1026,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         __threadfence_block();
         __syncthreads();
         row_pass<PASS_CORR_RHS>(c, io);
+        PROF(8);
         __threadfence_block();
         __syncthreads();
         gtv_ctrl(c);
@@ -810,13 +1038,17 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
         __threadfence_block();
         __syncthreads();
-        solve_blocks(d, w, w.rhs, lv);
+        PROF(5);
+        solve_dispatch(d, w, w.rhs, lv, lA);
+        PROF(6);
         apply_F(d, w, w.rhs, w.dx);
         __threadfence_block();
         __syncthreads();
         flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
         io.vmin = 1e300;
+        PROF(5);
         row_pass<PASS_STEP>(c, io);
+        PROF(9);
         double alpha = fmin(1.0, 0.99 * block_reduce(io.vmin, 2, red));
         __threadfence_block();
         __syncthreads();
@@ -830,6 +1062,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
             if (pmin >= 1e-3 * mu_new) break;
             alpha *= 0.8;
         }
+        PROF(10);
         io.alpha = alpha;
         row_pass<PASS_UPDATE>(c, io);
         for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
@@ -839,6 +1072,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         rows_swept += 5 * nrows_free;
         __threadfence_block();
         __syncthreads();
+        PROF(11);
     }
     if (!ok) {
         if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
@@ -848,7 +1082,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     double obj = 0;
     for (int it = tid; it < d.nb * 3 * M; it += QP_THREADS) {
         const int a = it / (3 * M), k = (it / M) % 3, m = it % M;
-        const double sc = pow(T[m + 1] - T[m], -5.0);
+        const double sc = w.segsc[m];
         const double* xs = ctrl + ((size_t)(first + a) * 3 + k) * d.oq + 6 * m;
         double q = 0;
         for (int i = 0; i < 6; ++i)
@@ -864,6 +1098,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         scal[SC_FLOPS] += flops;
         scal[SC_ROWS] += rows_swept;
     }
+    PROF_FLUSH(scal);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1058,7 +1293,7 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             return;
         }
         const int nk = 9 * bs, ld = nk + 1;
-        const size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 8) + 16;
+        const size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 16) + 16;
         hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
             for (int l = 0; l < biter; ++l)

@@ -54,7 +54,7 @@ struct DevSession {
     unsigned long long* counters;  // [K][4]: sfc samples, ...
 };
 
-enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6, SC_N = 8 };
+enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6, SC_PROF0 = 8, SC_N = 24 };  // SC_PROF0..: per-phase cycle counters (QP_PROFILE builds)
 enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
 // launchers (defined in the .hip files)

@@ -54,6 +54,7 @@ def lib():
         L.rbp_session_download.argtypes = [C.c_void_p, P(A.rbp_plan), A.c_int32_p, C.c_void_p]
         L.rbp_session_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.rbp_session_counters.argtypes = [C.c_void_p, P(A.rbp_counters), C.c_void_p]
+        L.rbp_session_scalars.argtypes = [C.c_void_p, A.c_double_p, C.c_int, C.c_void_p]
         L.rbp_session_destroy.argtypes = [C.c_void_p]
         L.rbp_session_destroy.restype = None
         _lib = L
@@ -62,7 +63,8 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_planner_update", "rbp_session_create", "rbp_session_run",
-    "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_version",
+    "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
+    "rbp_version",
     "rbp_last_error", "rbp_device_count",
 ]
 
@@ -144,6 +146,14 @@ class Session:
         if rc:
             raise RuntimeError(f"rbp_session_counters rc={rc}: {last_error()}")
         return {k: getattr(ct, k) for k, _ in ct._fields_}
+
+    def scalars(self, n=24, stream=None):
+        import numpy as np
+        out = np.zeros((self.K, n))
+        rc = lib().rbp_session_scalars(self._h, A.ptr(out, A.c_double_p), n, C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_scalars rc={rc}: {last_error()}")
+        return out
 
     def close(self):
         if self._h:

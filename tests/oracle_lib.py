@@ -22,7 +22,7 @@ class oracle_qp_options(C.Structure):
 
 
 class oracle_qp_report(C.Structure):
-    _fields_ = [("n_qp", C.c_int32), ("iters_total", C.c_int32), ("iters_max", C.c_int32), ("n_polished", C.c_int32),
+    _fields_ = [("n_qp", C.c_int32), ("iters_total", C.c_int32), ("iters_max", C.c_int32), ("n_polished", C.c_int32), ("n_loose", C.c_int32),
                 ("kkt_stationarity", C.c_double), ("kkt_primal_eq", C.c_double), ("kkt_primal_ineq", C.c_double),
                 ("kkt_dual_min", C.c_double), ("kkt_compl", C.c_double), ("duality_gap_rel", C.c_double),
                 ("flops", C.c_double)]

@@ -1,0 +1,19 @@
+"""Developer tool: per-phase cycle breakdown of qp_batch_kernel (library built with EXTRA=-DQP_PROFILE)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from swarm_simulator_amd import planner, _abi as A
+from swarm_simulator_amd.types import Param
+K = int(os.environ.get("K", "4"))
+p = Param.test_sweep()
+m, worlds, plans = bench.build_inputs(list(range(1, K + 1)), 64, p)
+s = planner.Session(worlds, [m] * K, p, plans)
+s.run(); st = s.download()
+sc = s.scalars()
+names = ["misc/update-tail", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "CORR sweep", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
+tot = sc[:, 8:20].sum(1)
+print("status", st, "iters", sc[:, 2])
+for i, n in enumerate(names):
+    print(f"{n:18s} {sc[:, 8 + i].mean() / 1e8 * 1e3:9.2f} ms (100 MHz clock)  {100 * sc[:, 8 + i].sum() / tot.sum():5.1f} %")
+print("total", tot.mean() / 1e8 * 1e3, "ms per mission")
