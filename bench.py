@@ -95,7 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--agents", type=int, default=64, help="mission_<N>agents_15.json (64 = headline, 16 = C2)")
-    ap.add_argument("--missions-per-gpu", type=int, default=50, help="maps planned per step on each GPU (the sweep has 50)")
+    ap.add_argument("--missions-per-gpu", type=int, default=250,
+                    help="missions in flight per step on each GPU: 250 = five passes of the reference's 50-map sweep, "
+                         "one workgroup per CU (256 CUs); 50 = exactly one sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -168,8 +170,9 @@ def main():
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N}-agent random_forest mission (mission_{N}agents_15.json) x {K} maps/GPU of the "
-                                   f"50-map sweep, sequential=true batch_size=4 (plan_rbp_test.launch)",
+            "config": {"workload": f"{N}-agent random_forest mission (mission_{N}agents_15.json) on worlds/map1..50.bt, {K} "
+                                   f"missions in flight per GPU ({K / 50:g} passes of the 50-map sweep), sequential=true "
+                                   f"batch_size=4 (plan_rbp_test.launch)",
                        "agents": N, "segments": M, "missions_per_gpu": K, "parallelism": f"missions sharded over {world_size} GPU(s)",
                        "all_missions_ok": not any(status)},
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},

@@ -20,6 +20,10 @@
 
 #include "rbp_dev.h"
 
+// The QP is tolerance-judged floating point: allow FMA contraction here (the Makefile disables it globally because
+// corridor.hip must round exactly like the reference's float32 code).
+#pragma clang fp contract(fast)
+
 #define QP_THREADS 512
 #define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
 #define QP_MAX_ITERS 80
@@ -78,13 +82,14 @@ struct QpWs {
     double *boxlo, *boxhi;          // [nb][M][3]
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
+    int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
 };
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + 5 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
-               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64;
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2;
     return n;
 }
 
@@ -113,6 +118,9 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.Dk = p, p += (size_t)(d.M + 1) * 9;
     w.Ek = p, p += (size_t)(d.M + 1) * 9;
     w.segsc = p, p += d.M;
+    w.flist = (int*)p;
+    w.fcnt = w.flist + (size_t)nbmax * d.M * d.N;
+    w.fbase = w.fcnt + (size_t)nbmax * d.M;
     return w;
 }
 
@@ -319,13 +327,14 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 }
             }
         }
-        // frozen neighbours
+        // frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped)
         const double ra = c.radius[qa];
-        int fi = 0;
-        for (int f = 0; f < N; ++f) {
-            if (f >= d.first && f < d.first + d.nb) continue;
-            const size_t r = d.nbnd + ((size_t)a * d.NF + fi) * oq + j6;
-            ++fi;
+        const int cnt = w.fcnt[a * d.M + seg];
+        const int* fl = w.flist + (size_t)(a * d.M + seg) * N;
+        const size_t rbase = d.nbnd + (size_t)w.fbase[a * d.M + seg] * 6 + (j6 - 6 * seg);
+        for (int idx = 0; idx < cnt; ++idx) {
+            const int f = fl[idx];
+            const size_t r = rbase + (size_t)idx * 6;
             const bool a_first = qa < f;
             const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * d.M + seg) * 3;
             const double sg = a_first ? 1.0 : -1.0;
@@ -935,6 +944,52 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     __threadfence_block();
     __syncthreads();
 
+    // ---- presolve: a frozen-neighbour row  sg*n.(d_f - x_a) >= r_a + r_f  is implied by the SFC bounds of (a, segment) when
+    // its slack is positive for EVERY x_a in the box; such rows cannot be active and are dropped (exact: the feasible
+    // set is unchanged).  Per (agent, segment) the surviving neighbours are listed; ~72 % of the rows go away on the
+    // 64-agent missions.
+    for (int it = tid; it < nb * M; it += QP_THREADS) {
+        const int a = it / M, seg = it % M, qa = first + a;
+        const double ra = c.radius[qa];
+        const double* lo = w.boxlo + ((size_t)a * M + seg) * 3;
+        const double* hi = w.boxhi + ((size_t)a * M + seg) * 3;
+        int cnt = 0;
+        int* fl = w.flist + (size_t)it * N;
+        for (int f = 0; f < N; ++f) {
+            if (f >= first && f < first + nb) continue;
+            const bool a_first = qa < f;
+            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
+            const double sg = a_first ? 1.0 : -1.0;
+            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
+            const double mx = fmax(n0 * lo[0], n0 * hi[0]) + fmax(n1 * lo[1], n1 * hi[1]) + fmax(n2 * lo[2], n2 * hi[2]);
+            const double rr = ra + c.radius[f];
+            bool keep = false;
+            for (int i = 0; i < 6; ++i) {
+                const int j6 = 6 * seg + i;
+                const double nd = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
+                                  n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6];
+                if (!(nd - rr - mx > 1e-6)) keep = true;
+            }
+            if (keep) fl[cnt++] = f;
+        }
+        w.fcnt[it] = cnt;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, free_rows = 0;
+        for (int it = 0; it < nb * M; ++it) {
+            w.fbase[it] = acc;
+            acc += w.fcnt[it];
+            const int seg = it % M;
+            free_rows += w.fcnt[it] * ((seg == 0 || seg == M - 1) ? (M == 1 ? 0 : 3) : 6);
+        }
+        *flag = free_rows;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int frozen_free_rows = *flag;
+    __syncthreads();
     PROF_DECL;
     PassIO io;
     io.mu0 = 1e-2, io.s_floor = 1e-2, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
@@ -950,7 +1005,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     __threadfence_block();
     __syncthreads();
 
-    const double nrows_free = (double)(d.nrows - (size_t)6 * (6 * d.nb + d.nb * d.NF + d.npb));
+    const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
     bool ok = false;
     int it_count = 0;
     double flops = 0, rows_swept = 0;

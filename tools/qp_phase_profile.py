@@ -7,7 +7,7 @@ from swarm_simulator_amd import planner, _abi as A
 from swarm_simulator_amd.types import Param
 K = int(os.environ.get("K", "4"))
 p = Param.test_sweep()
-m, worlds, plans = bench.build_inputs(list(range(1, K + 1)), 64, p)
+m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), 64, p)
 s = planner.Session(worlds, [m] * K, p, plans)
 s.run(); st = s.download()
 sc = s.scalars()
