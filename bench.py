@@ -179,7 +179,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "qp_batch_kernel", "achieved": qp_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "flops_per_step": ct["qp_flops"], "ipm_iterations_per_step": ct["qp_ipm_iters"],
-                         "constraint_rows_swept_per_step": ct["qp_constraint_rows"]},
+                         "constraint_rows_swept_per_step": ct["qp_constraint_rows"],
+                         "batch_qps_per_step": ct["qp_solves"], "batch_qps_polished_per_step": ct["qp_polished"]},
             "roofline_sfc": {"bound": "hbm", "kernel": "sfc_kernel", "achieved": sfc_bytes / (corridor_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s (reference-equivalent sample bytes, not physical)",
                              "frac": sfc_bytes / (corridor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "samples_per_step": ct["sfc_samples"]},

@@ -149,6 +149,7 @@ typedef struct rbp_counters {
     double qp_ipm_iters;    /* interior-point iterations summed over QPs */
     double qp_solves;       /* number of batch QPs solved */
     double qp_constraint_rows; /* inequality rows swept (rows x passes) */
+    double qp_polished;     /* batch QPs whose active-set polish was accepted (the rest keep the interior-point answer) */
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 

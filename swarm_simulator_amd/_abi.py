@@ -63,7 +63,7 @@ class rbp_plan(C.Structure):
 
 class rbp_counters(C.Structure):
     _fields_ = [("sfc_samples", C.c_double), ("qp_flops", C.c_double), ("qp_ipm_iters", C.c_double),
-                ("qp_solves", C.c_double), ("qp_constraint_rows", C.c_double)]
+                ("qp_solves", C.c_double), ("qp_constraint_rows", C.c_double), ("qp_polished", C.c_double)]
 
 
 class rbp_mission_buf(C.Structure):

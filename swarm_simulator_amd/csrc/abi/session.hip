@@ -138,6 +138,7 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
     d.p.iteration = param->iteration, d.p.time_scale = param->time_scale;
+    d.p.polish = getenv("RBP_NO_POLISH") ? 0 : 1;  // diagnostics only: interior-point answer without the active-set polish
 
     Arena& A = s->arena;
     s->worlds_h.resize(K);
@@ -317,6 +318,7 @@ int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
         out->qp_ipm_iters += sc[(size_t)k * SC_N + SC_IPM_ITERS];
         out->qp_solves += sc[(size_t)k * SC_N + SC_QP_SOLVED];
         out->qp_constraint_rows += sc[(size_t)k * SC_N + SC_ROWS];
+        out->qp_polished += sc[(size_t)k * SC_N + SC_POLISHED];
     }
     return RBP_OK;
 }

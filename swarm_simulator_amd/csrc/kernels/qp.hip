@@ -27,6 +27,8 @@
 #define QP_THREADS 512
 #define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
 #define QP_MAX_ITERS 80
+// LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
+#define POLISH_LDS_DOUBLES (2 * 36 * 36 + 96 * 97 / 2 + 128 + 128 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
 
 namespace {
 
@@ -83,13 +85,15 @@ struct QpWs {
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
     int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
+    double* polish;                 // PolishWs storage
 };
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + 5 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
-               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2;
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2 +
+               /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8);
     return n;
 }
 
@@ -121,6 +125,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.flist = (int*)p;
     w.fcnt = w.flist + (size_t)nbmax * d.M * d.N;
     w.fbase = w.fcnt + (size_t)nbmax * d.M;
+    w.polish = p + ((size_t)nbmax * d.M * (d.N + 2) + 1) / 2 + 2;
     return w;
 }
 
@@ -212,7 +217,7 @@ __device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
 // only checked once (presolve).  Work item = one free control point of one batch agent (all its bound and frozen
 // rows), then one (pair, control point).
 // ------------------------------------------------------------------------------------------------------------
-enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE };
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY };
 
 struct PassIO {
     // inputs
@@ -221,7 +226,12 @@ struct PassIO {
     double sum0, sum1, sum2, vmax, vmin;
 };
 
+#define QP_POLISH_PART 1
+#include "qp_polish.inc"
+#undef QP_POLISH_PART
+
 struct RowCtx {
+    const PolishWs* pw;
     const DevSession* S;
     int mission;
     QpDims d;
@@ -281,6 +291,19 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         w.z[r] += io.alpha * w.dz[r];
     } else if (PASS == PASS_PRESOLVE) {
         io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
+    } else if (PASS == PASS_CAND) {
+        const double s = w.s[r], z = w.z[r];
+        wgt = (z > s || s < 1e-6) ? 1.0 : 0.0;  // candidate for the active set
+        w.cc[r] = wgt;
+        v = slack;
+    } else if (PASS == PASS_VERIFY) {
+        const double sn = slack - gdx;  // slack at x + dx
+        w.ds[r] = sn;
+        io.vmax = fmax(io.vmax, -sn);
+        if (sn < -1e-11 && w.cc[r] == 0.0) {  // violated row that is not a candidate yet
+            w.cc[r] = 1.0;
+            wgt = 1.0;
+        }
     }
 }
 
@@ -303,7 +326,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         for (int k = 0; k < 3; ++k) {
             xa[k] = c.ctrl[((size_t)qa * 3 + k) * oq + j6];
             da[k] = (PASS == PASS_AFF) ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
-            dd[k] = (PASS == PASS_STEP) ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = (PASS == PASS_STEP || PASS == PASS_VERIFY) ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
         // bounds
@@ -317,6 +340,9 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
                 double wgt = 0, v = 0;
                 row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, wgt, v);
+                if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0)
+                    emit_cand(d, w, *c.pw, r, j6, a, -1, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack,
+                              (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo);
                 if (accum) {
                     const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);  // diagonal slots of the packed 3x3
                     if (PASS == PASS_BUILD) {
@@ -344,6 +370,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             const double slack = n0 * (f0 - xa[0]) + n1 * (f1 - xa[1]) + n2 * (f2 - xa[2]) - (ra + c.radius[f]);
             double wgt = 0, v = 0;
             row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
+            if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0);
             if (accum) {
                 if (PASS == PASS_BUILD) {
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
@@ -389,13 +416,14 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                  n1 * (w.dxa[((size_t)a * 3 + 1) * oq + j6] - w.dxa[((size_t)b * 3 + 1) * oq + j6]) +
                  n2 * (w.dxa[((size_t)a * 3 + 2) * oq + j6] - w.dxa[((size_t)b * 3 + 2) * oq + j6]);
         }
-        if (PASS == PASS_STEP) {
+        if (PASS == PASS_STEP || PASS == PASS_VERIFY) {
             gd = n0 * (w.dx[((size_t)a * 3 + 0) * oq + j6] - w.dx[((size_t)b * 3 + 0) * oq + j6]) +
                  n1 * (w.dx[((size_t)a * 3 + 1) * oq + j6] - w.dx[((size_t)b * 3 + 1) * oq + j6]) +
                  n2 * (w.dx[((size_t)a * 3 + 2) * oq + j6] - w.dx[((size_t)b * 3 + 2) * oq + j6]);
         }
         double wgt = 0, v = 0;
         row_op<PASS>(slack, ga, gd, r, w, io, wgt, v);
+        if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0);
         if (accum) {
             double* acc = w.pracc + (size_t)it * 12;
             if (PASS == PASS_BUILD) {
@@ -862,6 +890,10 @@ __device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, doub
     solve_blocks(d, w, rhs, lv, lA);
 }
 
+#define QP_POLISH_PART 2
+#include "qp_polish.inc"
+#undef QP_POLISH_PART
+
 // ------------------------------------------------------------------------------------------------------------
 // build_dummy (rbp_planner.hpp:513-549): control points of the waypoint-constant trajectory.  Used as `dummy`
 // in sequential mode and as the interior-point warm start in every mode.
@@ -911,6 +943,9 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     double* lv = lC + (size_t)d.nk * d.ld;  // 2*nk
     double* red = lv + 2 * d.nk;            // 16
     int* flag = (int*)(red + 16);
+    // polish reuses the block area from lds[0]; its reduction scratch sits behind its own carve (see launch_planner)
+    double* red2 = lds + POLISH_LDS_DOUBLES;
+    int* flag2 = (int*)(red2 + 16);
 
     mission_constants(d, T, const_cast<QpWs&>(w));
 
@@ -1133,6 +1168,26 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
         return;
     }
+    // ---- active-set polish (nk <= 36 path)
+    int polished = 0;
+    if (d.nk <= 36 && S.p.polish) {
+        PolishWs pw;
+        pw.cand = (Cand*)w.polish;
+        pw.V = w.polish + 128 * 14;
+        pw.Sg = pw.V + (size_t)129 * d.nj * d.nk;
+        pw.ncand = (int*)(pw.Sg + 128 * 128);
+        c.pw = &pw;
+        int acc = 0;
+        switch (d.nk) {
+            case 9: acc = polish_qp<9>(c, io, pw, lds, red2, flag2); break;
+            case 18: acc = polish_qp<18>(c, io, pw, lds, red2, flag2); break;
+            case 27: acc = polish_qp<27>(c, io, pw, lds, red2, flag2); break;
+            default: acc = polish_qp<36>(c, io, pw, lds, red2, flag2); break;
+        }
+        polished = acc == 0 ? 1 : 0;
+        if (acc != 0 && tid == 0) scal[7] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
+        __syncthreads();
+    }
     // objective of this batch: sum x' Q_p x  (cplex.getObjValue, :164)
     double obj = 0;
     for (int it = tid; it < d.nb * 3 * M; it += QP_THREADS) {
@@ -1150,6 +1205,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         scal[SC_TOTAL_COST] += obj;
         scal[SC_IPM_ITERS] += it_count;
         scal[SC_QP_SOLVED] += 1;
+        scal[SC_POLISHED] += polished;
         scal[SC_FLOPS] += flops;
         scal[SC_ROWS] += rows_swept;
     }
@@ -1348,7 +1404,8 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             return;
         }
         const int nk = 9 * bs, ld = nk + 1;
-        const size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 16) + 16;
+        size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 16) + 16;
+        if (nk <= 36) lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 16) + 16);
         hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
             for (int l = 0; l < biter; ++l)

@@ -28,6 +28,7 @@ struct DevParam {
     double world_min[3], world_max[3];
     double box_xy_res, box_z_res, downwash;
     int sequential, batch_size, batch_iter, iteration, time_scale;
+    int polish;  // 1: active-set polish after the interior-point solve (default)
 };
 
 // per-session pointers handed to kernels by value

@@ -15,8 +15,8 @@ from tests.common import BIG_CASES, MID_CASES, SMALL_CASES, Case, rsfc_hash
 
 pytestmark = pytest.mark.gpu
 
-CTRL_TOL = 5e-3   # metres; interior-point answer (no active-set polish on the GPU yet) vs polished optimum, compounded over batches
-OBJ_RTOL = 2e-5   # IPM-only answer on the GPU for now (mu <= 1e-10 x ~58k rows); the oracle is polished to 1e-10
+CTRL_TOL = 2e-6   # metres, sup norm over all control points: GPU (IPM + active-set polish) vs the oracle's certified optimum
+OBJ_RTOL = 1e-8
 FEAS_TOL = 1e-8
 
 
