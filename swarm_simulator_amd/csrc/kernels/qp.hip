@@ -24,11 +24,13 @@
 // corridor.hip must round exactly like the reference's float32 code).
 #pragma clang fp contract(fast)
 
+#ifndef QP_THREADS
 #define QP_THREADS 512
+#endif
 #define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
 #define QP_MAX_ITERS 80
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
-#define POLISH_LDS_DOUBLES (2 * 36 * 36 + 96 * 97 / 2 + 128 + 128 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
+#define POLISH_LDS_DOUBLES (96 * 97 / 2 + 128 + 128 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
 
 namespace {
 
@@ -80,7 +82,7 @@ struct QpWs {
     double *dx, *dxa, *cvec;        // [nb*3*oq]
     double *rbase, *rhs;            // [(M-1)*nk]
     double *Td, *To;                // [(M-1)][nk*nk], [(M-2)][nk*nk]
-    double *Lf;                     // [(M-1)][4][nk*nk] factor blocks in lane-friendly layouts (wave-register path)
+    double *Lf;                     // [(M-1)][2][nk*nk]: L_jj and L_{j+1,j}, both stored [k][r] (element (r,k) at k*nk + r)
     double *boxlo, *boxhi;          // [nb][M][3]
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
@@ -91,7 +93,7 @@ struct QpWs {
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
-               2 * (size_t)d.nj * d.nk + 5 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
+               2 * (size_t)d.nj * d.nk + 3 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2 +
                /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8);
     return n;
@@ -115,7 +117,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.rhs = p, p += (size_t)dm.nj * dm.nk;
     w.Td = p, p += (size_t)dm.nj * dm.nk * dm.nk;
     w.To = p, p += (size_t)(dm.nj > 1 ? dm.nj - 1 : 1) * dm.nk * dm.nk;
-    w.Lf = p, p += 4 * (size_t)dm.nj * dm.nk * dm.nk;
+    w.Lf = p, p += 2 * (size_t)dm.nj * dm.nk * dm.nk;
     w.boxlo = p, p += (size_t)nbmax * d.M * 3;
     w.boxhi = p, p += (size_t)nbmax * d.M * 3;
     w.Lk = p, p += (size_t)(d.M + 1) * 9;
@@ -718,10 +720,10 @@ __device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double
 // substitutions run in ONE wavefront with matrix rows held in VGPRs (lane r = row r, NK doubles per block) and
 // v_readlane broadcasts instead of LDS traffic: every step of the dependent chains costs a few issue cycles
 // instead of an LDS round trip, and no workgroup barrier is needed inside a knot.
-//   Lf[j][0] = L_jj     stored [k][r] (lane r reads its row,    coalesced)
-//   Lf[j][1] = L_jj     stored [r][k] (lane r reads its column, coalesced)   -> back substitution
-//   Lf[j][2] = L_{j+1,j} stored [k][r] (row r)                               -> forward elimination
-//   Lf[j][3] = L_{j+1,j} stored [r][k] (column r)                            -> backward elimination
+//   Lf[j][0] = L_jj      stored [k][r] (lane r writes its row coalesced)
+//   Lf[j][1] = L_{j+1,j} stored [k][r]
+// The substitutions stage these blocks through LDS (prefetched by the otherwise idle waves) and read rows or
+// columns from there.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double rl(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -762,14 +764,10 @@ __device__ bool wave_factor(const QpDims& d, const QpWs& w) {
             for (int k = c + 1; k < NK; ++k) a[k] -= a[c] * rl(a[c], k);
         }
         if (!ok) return false;
-        double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
+        double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         if (act) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const double v = k <= r ? a[k] : 0.0;
-                L0[k * NK + r] = v;            // [k][r]: row access
-                L0[NK * NK + r * NK + k] = v;  // [r][k]: column access by lane k later
-            }
+            for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
         }
         if (j + 1 < d.nj) {
             // b <- row r of T_{j+1,j} = blockdiag(E_{j+1}')  (assemble_blocks: rows u_{j+1}, cols u_j), then b <- b L_jj^{-T}
@@ -785,71 +783,91 @@ __device__ bool wave_factor(const QpDims& d, const QpWs& w) {
             }
             if (act) {
 #pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    L0[2 * NK * NK + k * NK + r] = b[k];
-                    L0[3 * NK * NK + r * NK + k] = b[k];
-                }
+                for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = b[k];
             }
         }
     }
     return true;
 }
 
+// Block substitutions T du = rhs with the factor blocks STAGED THROUGH LDS: waves 1.. prefetch the two blocks of step
+// s+1 (coalesced global reads into a double buffer) while wave 0 runs step s out of LDS with its row (forward) or
+// column (backward) in VGPRs.  rhs lives in LDS for the whole solve.  lds: 4 blocks of NK*(NK+1) + nj*NK doubles.
 template <int NK>
-__device__ void wave_solve(const QpDims& d, const QpWs& w, double* rhs) {
-    const int r = threadIdx.x & 63;
-    const bool act = r < NK;
-    const int rr = act ? r : 0;
-    double a[NK], b[NK];
+__device__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
+    constexpr int LDP = NK + 1, BLK = NK * LDP;
+    const int tid = threadIdx.x, nj = d.nj, nsteps = 2 * nj;
+    double* vec = lds + 4 * BLK;  // nj*NK
+    for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
+    auto stage = [&](int s, double* buf, int t0, int nt) {
+        const int jb = s < nj ? s : 2 * nj - 1 - s;
+        const double* Ld = w.Lf + (size_t)jb * 2 * NK * NK;
+        const double* Lo = s < nj ? (jb > 0 ? w.Lf + (size_t)(jb - 1) * 2 * NK * NK + NK * NK : nullptr)
+                                  : (jb + 1 < nj ? Ld + NK * NK : nullptr);
+        for (int it = t0; it < NK * NK; it += nt) {
+            const int o = (it / NK) * LDP + it % NK;  // [k][r] kept: element (r,k) at k*LDP + r
+            buf[o] = Ld[it];
+            if (Lo) buf[BLK + o] = Lo[it];
+        }
+    };
+    stage(0, lds, tid, QP_THREADS);
+    __syncthreads();
+    const int r = tid & 63;
+    const int rr = r < NK ? r : 0;
     double prev = 0;
-    for (int j = 0; j < d.nj; ++j) {  // forward: L y = rhs
-        const double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
+    for (int s = 0; s < nsteps; ++s) {
+        double* buf = lds + (s & 1) * 2 * BLK;
+        if (tid >= 64) {
+            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * 2 * BLK, tid - 64, QP_THREADS - 64);
+        } else {
+            const int jb = s < nj ? s : 2 * nj - 1 - s;
+            double a[NK], b[NK];
+            double v = vec[jb * NK + rr];
+            if (s < nj) {  // forward: row r of L_jj and of L_{jb,jb-1}
 #pragma unroll
-        for (int k = 0; k < NK; ++k) a[k] = L0[k * NK + rr];
-        double v = rhs[(size_t)j * NK + rr];
-        if (j > 0) {
-            const double* Lo = w.Lf + (size_t)(j - 1) * 4 * NK * NK + 2 * NK * NK;
+                for (int k = 0; k < NK; ++k) a[k] = buf[k * LDP + rr];
+                if (jb > 0) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) b[k] = Lo[k * NK + rr];
+                    for (int k = 0; k < NK; ++k) b[k] = buf[BLK + k * LDP + rr];
 #pragma unroll
-            for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                    for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                }
+                double dg = 1.0;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
+                const double inv = 1.0 / dg;
+#pragma unroll
+                for (int c = 0; c < NK; ++c) {
+                    const double xc = rl(v, c) * rl(inv, c);
+                    v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
+                }
+            } else {  // backward: column r of L_jj (a[k] = L[k][r]) and of L_{jb+1,jb}
+#pragma unroll
+                for (int k = 0; k < NK; ++k) a[k] = buf[rr * LDP + k];
+                if (jb + 1 < nj) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) b[k] = buf[BLK + rr * LDP + k];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                }
+                double dg = 1.0;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
+                const double inv = 1.0 / dg;
+#pragma unroll
+                for (int c = NK - 1; c >= 0; --c) {
+                    const double xc = rl(v, c) * rl(inv, c);
+                    v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
+                }
+            }
+            prev = v;
+            if (r < NK) vec[jb * NK + r] = v;
         }
-        double dg = 1.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-        const double inv = 1.0 / dg;
-#pragma unroll
-        for (int c = 0; c < NK; ++c) {
-            const double xc = rl(v, c) * rl(inv, c);
-            v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
-        }
-        prev = v;
-        if (act) rhs[(size_t)j * NK + r] = v;
+        __syncthreads();
     }
-    for (int j = d.nj - 1; j >= 0; --j) {  // backward: L' x = y
-        const double* L0 = w.Lf + (size_t)j * 4 * NK * NK;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) a[k] = L0[NK * NK + k * NK + rr];  // a[k] = L[k][r]
-        double v = prev;  // == rhs_j for the last knot; overwritten below otherwise
-        if (j + 1 < d.nj) {
-            v = rhs[(size_t)j * NK + rr];
-#pragma unroll
-            for (int k = 0; k < NK; ++k) b[k] = L0[3 * NK * NK + k * NK + rr];  // b[k] = L_{j+1,j}[k][r]
-#pragma unroll
-            for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
-        }
-        double dg = 1.0;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-        const double inv = 1.0 / dg;
-#pragma unroll
-        for (int c = NK - 1; c >= 0; --c) {
-            const double xc = rl(v, c) * rl(inv, c);
-            v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
-        }
-        prev = v;
-        if (act) rhs[(size_t)j * NK + r] = v;
-    }
+    for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
+    __threadfence_block();
+    __syncthreads();
 }
 
 __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
@@ -875,16 +893,12 @@ __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, doub
 
 __device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
     if (d.nk <= 36) {
-        if (threadIdx.x < 64) {
-            switch (d.nk) {
-                case 9: wave_solve<9>(d, w, rhs); break;
-                case 18: wave_solve<18>(d, w, rhs); break;
-                case 27: wave_solve<27>(d, w, rhs); break;
-                default: wave_solve<36>(d, w, rhs); break;
-            }
+        switch (d.nk) {  // lA = start of the dynamic LDS region (the three block buffers are free between factorisations)
+            case 9: solve_staged<9>(d, w, rhs, lA); break;
+            case 18: solve_staged<18>(d, w, rhs, lA); break;
+            case 27: solve_staged<27>(d, w, rhs, lA); break;
+            default: solve_staged<36>(d, w, rhs, lA); break;
         }
-        __threadfence_block();
-        __syncthreads();
         return;
     }
     solve_blocks(d, w, rhs, lv, lA);
@@ -936,16 +950,18 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     const double* T = S.T + (size_t)mission * (M + 1);
     double* scal = S.scalars + (size_t)mission * SC_N;
 
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    // dynamic LDS: [0,32) reduction scratch + flags (always live), then a work area shared in turn by the block
+    // factorisation (3 blocks), the staged substitutions (4 padded blocks + rhs) and the polish
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    double* red = lds_raw;  // 16
+    int* flag = (int*)(lds_raw + 16);
+    double* lds = lds_raw + 32;
     double* lA = lds;
     double* lB = lA + (size_t)d.nk * d.ld;
     double* lC = lB + (size_t)d.nk * d.ld;
     double* lv = lC + (size_t)d.nk * d.ld;  // 2*nk
-    double* red = lv + 2 * d.nk;            // 16
-    int* flag = (int*)(red + 16);
-    // polish reuses the block area from lds[0]; its reduction scratch sits behind its own carve (see launch_planner)
-    double* red2 = lds + POLISH_LDS_DOUBLES;
-    int* flag2 = (int*)(red2 + 16);
+    double* red2 = red;
+    int* flag2 = flag;
 
     mission_constants(d, T, const_cast<QpWs&>(w));
 
@@ -1185,6 +1201,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
             default: acc = polish_qp<36>(c, io, pw, lds, red2, flag2); break;
         }
         polished = acc == 0 ? 1 : 0;
+        PROF(0);
         if (acc != 0 && tid == 0) scal[7] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
         __syncthreads();
     }
@@ -1404,8 +1421,11 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             return;
         }
         const int nk = 9 * bs, ld = nk + 1;
-        size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 16) + 16;
-        if (nk <= 36) lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 16) + 16);
+        size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 32) + 16;
+        if (nk <= 36) {
+            lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 2 * 36 * 36 + 32) + 16);
+            lds = std::max(lds, sizeof(double) * ((size_t)4 * nk * (nk + 1) + (size_t)(M - 1) * nk + 64));
+        }
         hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
             for (int l = 0; l < biter; ++l)

@@ -36,7 +36,7 @@ def lib():
     """Load lib/librbp_hip.so; fails loudly if it was not built."""
     global _lib
     if _lib is None:
-        path = os.path.join(A.LIB_DIR, "librbp_hip.so")
+        path = os.environ.get("RBP_HIP_LIB") or os.path.join(A.LIB_DIR, "librbp_hip.so")  # env override: developer A/B builds
         if not os.path.exists(path):
             raise RbpLibraryMissing(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(path)
