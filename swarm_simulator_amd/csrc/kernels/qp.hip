@@ -731,106 +731,278 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// TWISTED ("burn at both ends") factorisation: wave 0 eliminates blocks 0 .. mid-1 upwards, wave 1 eliminates blocks
+// nj-1 .. mid+1 downwards, concurrently on two SIMDs; the middle block collects both Schur complements.  It halves the
+// length of the dependent chain (factor and substitutions alike) at no extra arithmetic.
+//   Lf[j][0] = L_jj                                    stored [k][r] (element (r,k) at k*NK + r)
+//   Lf[j][1] = coupling factor produced with block j:  j < mid: B_{j+1} = T_{j+1,j} L_jj^{-T}  (rows of block j+1)
+//                                                      j > mid: C_{j-1} = T_{j-1,j} L_jj^{-T}  (rows of block j-1)
+__device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
+
+// row r of the coupling block towards the next block of a chain.  T_{j+1,j}[r][k] = E_{knot j+1}[k%3][r%3] on the
+// (agent,dim) diagonal (assemble_blocks), T_{j-1,j} = T_{j,j-1}'.
 template <int NK>
-__device__ bool wave_factor(const QpDims& d, const QpWs& w) {
+__device__ __forceinline__ void coupling_row(const QpWs& w, int j, int dir, int rr, double (&b)[NK]) {
+    if (dir > 0) {
+        const double* E = w.Ek + 9 * (j + 1);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (k % 3) + (rr % 3)] : 0.0;
+    } else {
+        const double* E = w.Ek + 9 * j;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (rr % 3) + (k % 3)] : 0.0;
+    }
+}
+
+// a -= b B'  (b = row r of the coupling factor B, a = row r of the diagonal block; only a[k], k <= r, is needed).
+// MFMA version: the wave parks B in LDS, accumulates the lower 16x16 tiles of B B' with v_mfma_f64_16x16x4_f64
+// (A operand = B[16ti + (l&15)][4ks + (l>>4)], B operand = the same rows of tile tj, i.e. B' ), writes the tiles to an
+// LDS scratch in the C/D layout (col = l&15, row = (l>>4) + 4*reg) and reads its own row back.  ~60 instructions of
+// loop body instead of 1296 unrolled readlane-FMA pairs (which alone overflowed the 64 KB instruction cache).
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define SYRK_LDB (36 + 2)
+#define SYRK_LDU (48 + 2)
+#define SYRK_LDS_DOUBLES (48 * SYRK_LDB + 48 * SYRK_LDU)
+
+template <int NK>
+__device__ __forceinline__ void syrk_store_b(const double (&b)[NK], double* ldsB, int r) {
+    if (r < NK) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) ldsB[r * SYRK_LDB + k] = b[k];
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void syrk_mfma_accumulate(d4 (&acc)[6], const double* ldsB, int lane) {
+    constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int ks = 0; ks < KS; ++ks) {
+        double op[3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) op[t] = ldsB[(16 * t + li) * SYRK_LDB + 4 * ks + lk];
+        int idx = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj, ++idx) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[idx], 0, 0, 0);
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void syrk_apply(double (&a)[NK], const d4 (&acc)[6], double* ldsU, int lane, int rr) {
+    constexpr int NT = (NK + 15) / 16;
+    const int li = lane & 15, lk = lane >> 4;
+    int idx = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++idx)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ldsU[(16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li] = acc[idx][g];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NK>
+__device__ __forceinline__ void syrk_rows(double (&a)[NK], const double (&b)[NK], double* ldsW, int lane, int rr) {
+    double* ldsB = ldsW;
+    double* ldsU = ldsW + 48 * SYRK_LDB;
+    syrk_store_b<NK>(b, ldsB, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    d4 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = d4{0, 0, 0, 0};
+    syrk_mfma_accumulate<NK>(acc, ldsB, lane);
+    syrk_apply<NK>(a, acc, ldsU, lane, rr);
+}
+
+template <int NK>
+__device__ __forceinline__ bool chol_rows(double (&a)[NK]) {  // right-looking; a[c] = L[r][c] for lanes r >= c
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+        const double dcc = rl(a[c], c);
+        if (!(dcc > 0)) ok = false;
+        const double inv = 1.0 / sqrt(dcc);
+        a[c] *= inv;
+#pragma unroll
+        for (int k = c + 1; k < NK; ++k) a[k] -= a[c] * rl(a[c], k);
+    }
+    return ok;
+}
+
+// one chain: blocks j0, j0+dir, ... (count of them)
+template <int NK>
+__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW) {
     const int r = threadIdx.x & 63;
     const bool act = r < NK;
     const int rr = act ? r : 0;
     double a[NK], b[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) b[k] = 0;
-    bool ok = true;
-    for (int j = 0; j < d.nj; ++j) {
+    for (int i = 0, j = j0; i < count; ++i, j += dir) {
         const double* Tg = w.Td + (size_t)j * NK * NK;
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
-        if (j > 0) {  // a -= b B'  (b = row r of L_{j,j-1})
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                double sum = 0;
-#pragma unroll
-                for (int m = 0; m < NK; ++m) sum += b[m] * rl(b[m], k);
-                a[k] -= sum;
-            }
-        }
-        // right-looking Cholesky: after step c, a[c] holds L[r][c] for lanes r >= c
-#pragma unroll
-        for (int c = 0; c < NK; ++c) {
-            const double dcc = rl(a[c], c);
-            if (!(dcc > 0)) ok = false;
-            const double inv = 1.0 / sqrt(dcc);
-            a[c] *= inv;
-#pragma unroll
-            for (int k = c + 1; k < NK; ++k) a[k] -= a[c] * rl(a[c], k);
-        }
-        if (!ok) return false;
+        if (i > 0) syrk_rows<NK>(a, b, ldsW, r, rr);
+        if (!chol_rows<NK>(a)) return false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         if (act) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
         }
-        if (j + 1 < d.nj) {
-            // b <- row r of T_{j+1,j} = blockdiag(E_{j+1}')  (assemble_blocks: rows u_{j+1}, cols u_j), then b <- b L_jj^{-T}
-            const double* E = w.Ek + 9 * (j + 1);
+        // coupling towards the next block of the chain (the last one couples to the middle block): b <- Tn L_jj^{-T}
+        coupling_row<NK>(w, j, dir, rr, b);
 #pragma unroll
-            for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (k % 3) + (rr % 3)] : 0.0;
+        for (int c = 0; c < NK; ++c) {
+            const double xc = b[c] / rl(a[c], c);
+            b[c] = xc;
 #pragma unroll
-            for (int c = 0; c < NK; ++c) {
-                const double xc = b[c] / rl(a[c], c);
-                b[c] = xc;
+            for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
+        }
+        if (act) {
 #pragma unroll
-                for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
-            }
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = b[k];
-            }
+            for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = b[k];
         }
     }
     return true;
 }
 
-// Block substitutions T du = rhs with the factor blocks STAGED THROUGH LDS: waves 1.. prefetch the two blocks of step
-// s+1 (coalesced global reads into a double buffer) while wave 0 runs step s out of LDS with its row (forward) or
-// column (backward) in VGPRs.  rhs lives in LDS for the whole solve.  lds: 4 blocks of NK*(NK+1) + nj*NK doubles.
 template <int NK>
-__device__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
+__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW) {
+    const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
+    const bool act = r < NK;
+    const int rr = act ? r : 0;
+    double a[NK], b[NK];
+    const double* Tg = w.Td + (size_t)mid * NK * NK;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+    if (mid > 0) {
+        const double* Bm = w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) b[k] = Bm[k * NK + rr];
+        syrk_rows<NK>(a, b, ldsW, r, rr);
+    }
+    if (mid + 1 < d.nj) {
+        const double* Cm = w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) b[k] = Cm[k * NK + rr];
+        syrk_rows<NK>(a, b, ldsW, r, rr);
+    }
+    if (!chol_rows<NK>(a)) return false;
+    double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
+    }
+    return true;
+}
+
+// whole twisted factorisation; every thread of the workgroup calls it.  flag: LDS int.
+template <int NK>
+__device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds) {
+    const int wave = threadIdx.x >> 6, mid = twist_mid(d.nj);
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    bool ok = true;
+    // rows >= NK of the LDS copy of B are never written: clear them once (they only feed unused tile entries)
+    for (int i = threadIdx.x; i < 2 * SYRK_LDS_DOUBLES; i += QP_THREADS) lds[i] = 0.0;
+    __syncthreads();
+    if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds);
+    if (wave == 1 && d.nj - 1 - mid > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, d.nj - 1 - mid, -1, lds + SYRK_LDS_DOUBLES);
+    if (!ok && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
+    __threadfence_block();
+    __syncthreads();
+    if (*flag) return false;
+    if (wave == 0) {
+        if (!wave_factor_mid<NK>(d, w, lds) && threadIdx.x == 0) *flag = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return *flag == 0;
+}
+
+// Substitutions T du = rhs for the twisted factorisation, factor blocks STAGED THROUGH LDS: waves 2.. prefetch the
+// blocks of step s+1 (coalesced global reads into a double buffer) while waves 0 / 1 run step s of the left / right
+// chain out of LDS with a row (forward) or a column (backward) of each block in VGPRs.  rhs lives in LDS throughout.
+// lds: 2 x 4 blocks of NK*(NK+1) + nj*NK doubles.
+template <int NK>
+__device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
     constexpr int LDP = NK + 1, BLK = NK * LDP;
-    const int tid = threadIdx.x, nj = d.nj, nsteps = 2 * nj;
-    double* vec = lds + 4 * BLK;  // nj*NK
+    const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
+    const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
+    const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
+    double* vec = lds + 8 * BLK;    // nj*NK
     for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
+    // block indices handled at step s by the left / right wave (-1: idle)
+    auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
+    auto right_j = [&](int s) { return s < SF ? (s - (SF - nr) >= 0 ? nj - 1 - (s - (SF - nr)) : -1) : (s == SF ? -1 : (mid + 1 + (s - SF - 1) <= nj - 1 ? mid + 1 + (s - SF - 1) : -1)); };
+    auto copy_blk = [&](const double* src, double* dst, int t0, int nt) {
+        // all loads first, then the LDS stores (element (r,k) stays at k*LDP + r): keeps up to 8 loads in flight per lane
+        double tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = t0 + u * nt;
+            tmp[u] = it < NK * NK ? src[it] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = t0 + u * nt;
+            if (it < NK * NK) dst[(it / NK) * LDP + it % NK] = tmp[u];
+        }
+        for (int it = t0 + 8 * nt; it < NK * NK; it += nt) dst[(it / NK) * LDP + it % NK] = src[it];
+    };
     auto stage = [&](int s, double* buf, int t0, int nt) {
-        const int jb = s < nj ? s : 2 * nj - 1 - s;
-        const double* Ld = w.Lf + (size_t)jb * 2 * NK * NK;
-        const double* Lo = s < nj ? (jb > 0 ? w.Lf + (size_t)(jb - 1) * 2 * NK * NK + NK * NK : nullptr)
-                                  : (jb + 1 < nj ? Ld + NK * NK : nullptr);
-        for (int it = t0; it < NK * NK; it += nt) {
-            const int o = (it / NK) * LDP + it % NK;  // [k][r] kept: element (r,k) at k*LDP + r
-            buf[o] = Ld[it];
-            if (Lo) buf[BLK + o] = Lo[it];
+        const int jl = left_j(s), jr = right_j(s);
+        if (s == SF) {  // middle: L_mid, B_mid, C_mid
+            copy_blk(w.Lf + (size_t)mid * 2 * NK * NK, buf, t0, nt);
+            if (mid > 0) copy_blk(w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK, buf + BLK, t0, nt);
+            if (mid + 1 < nj) copy_blk(w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK, buf + 2 * BLK, t0, nt);
+            return;
+        }
+        const bool fwd = s < SF;
+        if (jl >= 0) {
+            copy_blk(w.Lf + (size_t)jl * 2 * NK * NK, buf, t0, nt);
+            // forward: B_jl = Lf[jl-1][1] (rows of block jl); backward: B_{jl+1} = Lf[jl][1]
+            if (fwd ? jl > 0 : true) copy_blk(w.Lf + (size_t)(fwd ? jl - 1 : jl) * 2 * NK * NK + NK * NK, buf + BLK, t0, nt);
+        }
+        if (jr >= 0) {
+            copy_blk(w.Lf + (size_t)jr * 2 * NK * NK, buf + 2 * BLK, t0, nt);
+            // forward: C_jr = Lf[jr+1][1] (rows of block jr); backward: C_{jr-1} = Lf[jr][1]
+            if (fwd ? jr + 1 < nj : true) copy_blk(w.Lf + (size_t)(fwd ? jr + 1 : jr) * 2 * NK * NK + NK * NK, buf + 3 * BLK, t0, nt);
         }
     };
     stage(0, lds, tid, QP_THREADS);
     __syncthreads();
-    const int r = tid & 63;
+    const int wave = tid >> 6, r = tid & 63;
     const int rr = r < NK ? r : 0;
-    double prev = 0;
+    double prev = 0;  // this chain's previous solution vector, element r
     for (int s = 0; s < nsteps; ++s) {
-        double* buf = lds + (s & 1) * 2 * BLK;
-        if (tid >= 64) {
-            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * 2 * BLK, tid - 64, QP_THREADS - 64);
-        } else {
-            const int jb = s < nj ? s : 2 * nj - 1 - s;
-            double a[NK], b[NK];
-            double v = vec[jb * NK + rr];
-            if (s < nj) {  // forward: row r of L_jj and of L_{jb,jb-1}
+        double* buf = lds + (s & 1) * 4 * BLK;
+        if (wave >= 2) {
+            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * 4 * BLK, tid - 128, QP_THREADS - 128);
+        } else if (s == SF) {
+            if (wave == 0) {  // middle block: forward with both neighbours, then backward
+                double a[NK], b[NK];
+                double v = vec[mid * NK + rr];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) a[k] = buf[k * LDP + rr];
-                if (jb > 0) {
+                if (mid > 0) {
 #pragma unroll
                     for (int k = 0; k < NK; ++k) b[k] = buf[BLK + k * LDP + rr];
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                    for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid - 1) * NK + k];
+                }
+                if (mid + 1 < nj) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) b[k] = buf[2 * BLK + k * LDP + rr];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid + 1) * NK + k];
                 }
                 double dg = 1.0;
 #pragma unroll
@@ -841,27 +1013,66 @@ __device__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double
                     const double xc = rl(v, c) * rl(inv, c);
                     v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
                 }
-            } else {  // backward: column r of L_jj (a[k] = L[k][r]) and of L_{jb+1,jb}
 #pragma unroll
-                for (int k = 0; k < NK; ++k) a[k] = buf[rr * LDP + k];
-                if (jb + 1 < nj) {
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = buf[BLK + rr * LDP + k];
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
-                }
-                double dg = 1.0;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-                const double inv = 1.0 / dg;
+                for (int k = 0; k < NK; ++k) a[k] = buf[rr * LDP + k];  // column r
 #pragma unroll
                 for (int c = NK - 1; c >= 0; --c) {
                     const double xc = rl(v, c) * rl(inv, c);
                     v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
                 }
+                if (r < NK) vec[mid * NK + r] = v;
             }
-            prev = v;
-            if (r < NK) vec[jb * NK + r] = v;
+        } else {
+            const bool fwd = s < SF;
+            const int jb = wave == 0 ? left_j(s) : right_j(s);
+            if (jb >= 0) {
+                const double* bl = buf + (wave == 0 ? 0 : 2 * BLK);
+                double a[NK], b[NK];
+                double v = vec[jb * NK + rr];
+                const bool first_bwd = !fwd && s == SF + 1;  // neighbour solution comes from the middle block (in LDS)
+                const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
+                if (fwd) {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) a[k] = bl[k * LDP + rr];
+                    if (has_nb) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) b[k] = bl[BLK + k * LDP + rr];
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) a[k] = bl[rr * LDP + k];
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) b[k] = bl[BLK + rr * LDP + k];
+                    if (first_bwd) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) v -= b[k] * vec[mid * NK + k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                    }
+                }
+                double dg = 1.0;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
+                const double inv = 1.0 / dg;
+                if (fwd) {
+#pragma unroll
+                    for (int c = 0; c < NK; ++c) {
+                        const double xc = rl(v, c) * rl(inv, c);
+                        v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = NK - 1; c >= 0; --c) {
+                        const double xc = rl(v, c) * rl(inv, c);
+                        v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
+                    }
+                }
+                prev = v;
+                if (r < NK) vec[jb * NK + r] = v;
+            }
         }
         __syncthreads();
     }
@@ -872,21 +1083,12 @@ __device__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double
 
 __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
     if (d.nk <= 36) {
-        if (threadIdx.x == 0) *flag = 0;
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            bool ok = true;
-            switch (d.nk) {
-                case 9: ok = wave_factor<9>(d, w); break;
-                case 18: ok = wave_factor<18>(d, w); break;
-                case 27: ok = wave_factor<27>(d, w); break;
-                default: ok = wave_factor<36>(d, w); break;
-            }
-            if (!ok && threadIdx.x == 0) *flag = 1;
+        switch (d.nk) {
+            case 9: return twisted_factor<9>(d, w, flag, lA);
+            case 18: return twisted_factor<18>(d, w, flag, lA);
+            case 27: return twisted_factor<27>(d, w, flag, lA);
+            default: return twisted_factor<36>(d, w, flag, lA);
         }
-        __threadfence_block();
-        __syncthreads();
-        return *flag == 0;
     }
     return factor_blocks(d, w, lA, lB, lC, flag);
 }
@@ -1423,8 +1625,8 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         const int nk = 9 * bs, ld = nk + 1;
         size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 32) + 16;
         if (nk <= 36) {
-            lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 2 * 36 * 36 + 32) + 16);
-            lds = std::max(lds, sizeof(double) * ((size_t)4 * nk * (nk + 1) + (size_t)(M - 1) * nk + 64));
+            lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 2 * 36 * 36 + 36 * 129 + 32) + 16);
+            lds = std::max(lds, sizeof(double) * ((size_t)8 * nk * (nk + 1) + (size_t)(M - 1) * nk + 64));
         }
         hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
