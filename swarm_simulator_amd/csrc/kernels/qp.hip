@@ -88,6 +88,7 @@ struct QpWs {
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
     int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
     double* polish;                 // PolishWs storage
+    double *rn0, *rn1, *rn2, *rhc;  // per frozen-neighbour row: signed normal and constant  (slack = rhc - rn . x_a)
 };
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
@@ -95,7 +96,8 @@ __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + 3 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2 +
-               /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8);
+               /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8) +
+               /* row constants */ 4 * (size_t)nbmax * N * d.oq;
     return n;
 }
 
@@ -128,6 +130,10 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.fcnt = w.flist + (size_t)nbmax * d.M * d.N;
     w.fbase = w.fcnt + (size_t)nbmax * d.M;
     w.polish = p + ((size_t)nbmax * d.M * (d.N + 2) + 1) / 2 + 2;
+    w.rn0 = w.polish + (128 * 14 + (size_t)129 * dm.nj * dm.nk + 128 * 128 + 8);
+    w.rn1 = w.rn0 + (size_t)nbmax * d.N * d.oq;
+    w.rn2 = w.rn1 + (size_t)nbmax * d.N * d.oq;
+    w.rhc = w.rn2 + (size_t)nbmax * d.N * d.oq;
     return w;
 }
 
@@ -355,21 +361,16 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 }
             }
         }
-        // frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped)
-        const double ra = c.radius[qa];
+        // frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped).
+        // Row constants (signed normal, rhs) were tabulated once per QP: the sweep is a pure stream over SoA arrays.
         const int cnt = w.fcnt[a * d.M + seg];
-        const int* fl = w.flist + (size_t)(a * d.M + seg) * N;
         const size_t rbase = d.nbnd + (size_t)w.fbase[a * d.M + seg] * 6 + (j6 - 6 * seg);
+#pragma unroll 2
         for (int idx = 0; idx < cnt; ++idx) {
-            const int f = fl[idx];
             const size_t r = rbase + (size_t)idx * 6;
-            const bool a_first = qa < f;
-            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * d.M + seg) * 3;
-            const double sg = a_first ? 1.0 : -1.0;
-            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
-            const double f0 = c.ctrl[((size_t)f * 3 + 0) * oq + j6], f1 = c.ctrl[((size_t)f * 3 + 1) * oq + j6],
-                         f2 = c.ctrl[((size_t)f * 3 + 2) * oq + j6];
-            const double slack = n0 * (f0 - xa[0]) + n1 * (f1 - xa[1]) + n2 * (f2 - xa[2]) - (ra + c.radius[f]);
+            const size_t fr = r - d.nbnd;
+            const double n0 = w.rn0[fr], n1 = w.rn1[fr], n2 = w.rn2[fr];
+            const double slack = w.rhc[fr] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
             double wgt = 0, v = 0;
             row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
             if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0);
@@ -1242,6 +1243,27 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     __threadfence_block();
     __syncthreads();
     const int frozen_free_rows = *flag;
+    __syncthreads();
+    // tabulate the constants of the surviving rows: n (sign applied) and rhc = n . d_f - (r_a + r_f)
+    for (int it = tid; it < nb * M * 6; it += QP_THREADS) {
+        const int as = it / 6, i = it % 6, a = as / M, seg = as % M, qa = first + a, j6 = 6 * seg + i;
+        const int cnt = w.fcnt[as];
+        const int* fl = w.flist + (size_t)as * N;
+        const size_t fr0 = (size_t)w.fbase[as] * 6 + i;
+        const double ra = c.radius[qa];
+        for (int idx = 0; idx < cnt; ++idx) {
+            const int f = fl[idx];
+            const bool a_first = qa < f;
+            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
+            const double sg = a_first ? 1.0 : -1.0;
+            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
+            const size_t fr = fr0 + (size_t)idx * 6;
+            w.rn0[fr] = n0, w.rn1[fr] = n1, w.rn2[fr] = n2;
+            w.rhc[fr] = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
+                        n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6] - (ra + c.radius[f]);
+        }
+    }
+    __threadfence_block();
     __syncthreads();
     PROF_DECL;
     PassIO io;
