@@ -165,6 +165,15 @@ def main():
         # factorisations/solves it logs (F = sum_factor 7/3 nk^3 per knot + sum_solve 4 nk^2 per knot);
         # a step launches (iterations x batches) QP kernels; achieved = flops per step / planner time per step.
         qp_tflops = ct["qp_flops"] / (planner_ms * 1e-3) / 1e12
+        # HBM-side bytes per qp_batch_kernel launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc.json
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if pmc.get("missions_per_gpu") == K and N == 64:
+                traffic = pmc["kernels"]["qp_batch_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         sfc_bytes = 4.0 * ct["sfc_samples"]
         out = {
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
@@ -177,7 +186,7 @@ def main():
                        "all_missions_ok": not any(status)},
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},
             "roofline": {"bound": "mfma", "kernel": "qp_batch_kernel", "achieved": qp_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_step": ct["qp_flops"], "ipm_iterations_per_step": ct["qp_ipm_iters"],
                          "constraint_rows_swept_per_step": ct["qp_constraint_rows"],
                          "batch_qps_per_step": ct["qp_solves"], "batch_qps_polished_per_step": ct["qp_polished"]},
