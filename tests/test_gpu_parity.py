@@ -78,6 +78,26 @@ def test_planner_vs_golden(name):
     assert obj <= float(g["evaluate"][0]) * (1 + OBJ_RTOL) + 1e-9   # no worse than the certified optimum
 
 
+@pytest.mark.parametrize("pkw", [dict(batch_size=8, iteration=2), dict(sequential=False)])
+def test_wide_batches_vs_oracle(pkw):
+    """batches of 8 agents (C5-style schedule; joint QP of 8 agents): block order 72 runs on the LDS-tiled path,
+    which has no active-set polish yet -> interior-point tolerance."""
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission("mission_8agents_15.json")
+    w = host.load_world("map5.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    assert O.planner_update(m, p, ref)[0] == 0
+    assert planner.Corridor(w, m, p).update(False, gpu)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu), pl.last_error
+    assert np.abs(ref.ctrl - gpu.ctrl).max() < 5e-3
+    assert abs(ref.total_cost - gpu.total_cost) < 1e-4 * max(1.0, abs(ref.total_cost))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < FEAS_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
 def test_planner_only_call_with_host_corridor():
     """RBPPlanner::update as a drop-in on a PlanResult whose corridor came from elsewhere (here: the golden)."""
     c = Case("s8_map5_seq4")
