@@ -11,14 +11,17 @@
 // the reference's own sample order (x outer, z inner), 64 samples per step, with a ballot to find the first
 // obstacle, so the early exit and the sample count are exactly the reference's.  Sample coordinates are
 // produced by the same double accumulation / float32 rounding / floor as the CPU path (bit-exact boxes);
-// per-axis voxel indices are cached in LDS so the inner loop is three ds_reads + one grid read.
-// The grid (0.94 MB float32) is L2-resident; reads along z are contiguous.
+// per-axis voxel indices are cached in LDS so the inner loop is three ds_reads + one occupancy read.  Four agents of a
+// mission share a workgroup and one LDS BITMASK of the grid (bit = dist < r - 1e-6, 29 KB for 101x101x23), built once per
+// workgroup with coalesced reads + ballots; agents whose radius differs from the group's first read the float grid.
 //
 // RSFC: one thread per (mission, pair, segment), float32 arithmetic in octomath's operation order
 // (compiled with -ffp-contract=off; HIP's float division and the f64 sqrt are correctly rounded).
 #include "rbp_dev.h"
 
-#define SFC_MAXS 1024  // max samples per axis (world extent / box resolution + 2)
+#define SFC_MAXS 512        // max samples per axis (world extent / box resolution + 2)
+#define SFC_WAVES 4         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
+#define SFC_MASK_WORDS 8192  // 262144 cells = 32 KB; larger grids fall back to reading the float grid
 
 namespace {
 
@@ -45,6 +48,7 @@ __device__ __forceinline__ int axis_keys(int* keys, double lo, double hi, double
 }
 
 struct SfcCtx {
+    const unsigned* mask;  // LDS occupancy bitmask (bit = dist < margin - 1e-6) or nullptr
     const float* grid;
     int dim[3], key_min[3];
     double rf, world_min[3], world_max[3], res[3];
@@ -82,8 +86,13 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
             if ((ix | iy | iz) < 0) {
                 hit = true;  // getDistance returns -1 outside the map
             } else {
-                float d = c.grid[((size_t)ix * ny + iy) * nz + iz];
-                hit = (double)d < c.margin_cmp;
+                const unsigned cell = ((unsigned)ix * ny + iy) * nz + iz;
+                if (c.mask) {
+                    hit = (c.mask[cell >> 5] >> (cell & 31)) & 1u;
+                } else {
+                    float d = c.grid[cell];
+                    hit = (double)d < c.margin_cmp;
+                }
             }
         }
         unsigned long long m = __ballot(hit);
@@ -155,12 +164,37 @@ __device__ void expand_box(SfcCtx& c, double* box, int lane) {
     }
 }
 
-__global__ __launch_bounds__(64) void sfc_kernel(DevSession s) {
-    const int mission = blockIdx.x / s.N, qi = blockIdx.x % s.N, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
+    const int groups = (s.N + SFC_WAVES - 1) / SFC_WAVES;
+    const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = (blockIdx.x % groups) * SFC_WAVES + wave;
     const int M = s.M, P = M + 1, MB = s.max_boxes;
-    __shared__ int keys[3][SFC_MAXS];
-    extern __shared__ int box_log[];  // [MB][P]
+    __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
+    __shared__ unsigned mask[SFC_MASK_WORDS];
+    extern __shared__ int box_log_all[];  // [SFC_WAVES][MB][P]
+    int* box_log = box_log_all + (size_t)wave * MB * P;
     const DevWorld w = s.worlds[mission];
+    // ---- occupancy bitmask of this mission's grid for the radius of the group's first agent, built once per workgroup
+    // with coalesced reads + ballots.  The SFC test only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per
+    // cell (29 KB for the 101x101x23 grid) replaces ~0.6 M float reads per agent from L2/MALL by LDS reads.
+    const int q0 = (blockIdx.x % groups) * SFC_WAVES;
+    const double radius0 = s.radius[(size_t)mission * s.N + q0];
+    const unsigned ncell = (unsigned)w.dim[0] * w.dim[1] * w.dim[2];
+    const bool mask_fits = ncell + 64 <= 32u * SFC_MASK_WORDS;
+    if (mask_fits) {
+        const double cmp0 = radius0 - SP_EPSILON_FLOAT;
+        for (unsigned base = wave * 64; base < ((ncell + 63) & ~63u); base += 64 * SFC_WAVES) {
+            const unsigned cell = base + lane;
+            const bool occ = cell < ncell && (double)w.dist[cell] < cmp0;
+            const unsigned long long b = __ballot(occ);
+            if (lane == 0) {
+                mask[base >> 5] = (unsigned)b;
+                mask[(base >> 5) + 1] = (unsigned)(b >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    if (qi >= s.N) return;
     SfcCtx c;
     c.grid = w.dist;
     c.rf = 1.0 / w.res;
@@ -168,12 +202,13 @@ __global__ __launch_bounds__(64) void sfc_kernel(DevSession s) {
     for (int a = 0; a < 3; ++a) {
         c.dim[a] = w.dim[a], c.key_min[a] = w.key_min[a];
         c.world_min[a] = s.p.world_min[a], c.world_max[a] = s.p.world_max[a];
-        c.keys[a] = keys[a];
+        c.keys[a] = keys_all[wave][a];
         c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0;
     }
     c.res[0] = c.res[1] = s.p.box_xy_res, c.res[2] = s.p.box_z_res;
     const double radius = s.radius[(size_t)mission * s.N + qi];
     c.margin_cmp = radius - SP_EPSILON_FLOAT;
+    c.mask = (mask_fits && radius == radius0) ? mask : nullptr;  // agents with another radius read the float grid
     c.samples = 0;
 
     const float* traj = s.init_traj + ((size_t)mission * s.N + qi) * P * 3;
@@ -223,7 +258,8 @@ __global__ __launch_bounds__(64) void sfc_kernel(DevSession s) {
             box_log[b * P + j] = is_point_in_box(pj, bx) ? 1 : 0;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // box_log is private to this wave
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         for (int b = 0; b < nbox; ++b)
             for (int j = 1; j < P; ++j)
@@ -330,8 +366,10 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
 void launch_corridor(const DevSession& s, hipStream_t st) {
     // updateObsBox() && updateRelBox() (:25): RSFC results are only meaningful if SFC succeeded; status keeps the
     // first error, with SFC errors taking precedence because sfc_kernel is enqueued first.
-    const size_t lds = sizeof(int) * (size_t)s.max_boxes * (s.M + 1);
-    hipLaunchKernelGGL(sfc_kernel, dim3(s.K * s.N), dim3(64), lds, st, s);
+    const size_t lds = sizeof(int) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1);
+    const int groups = (s.N + SFC_WAVES - 1) / SFC_WAVES;
+    hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
     const long long total = (long long)s.K * s.npair * s.M;
     if (total > 0) hipLaunchKernelGGL(rsfc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s);
 }
