@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     __syncthreads();
     PROF_DECL;
     PassIO io;
-    io.mu0 = 1e-2, io.s_floor = 1e-2, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
+    io.mu0 = 1e-1, io.s_floor = 1e-1, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
     // presolve: constant rows (pinned control points) must hold within 1e-6 (CPLEX default feasibility tolerance)
     io.vmax = 0;
     row_pass<PASS_PRESOLVE>(c, io);
