@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--missions-per-gpu", type=int, default=250,
                     help="missions in flight per step on each GPU: 250 = five passes of the reference's 50-map sweep, "
                          "one workgroup per CU (256 CUs); 50 = exactly one sweep")
+    ap.add_argument("--batch-size", type=int, default=4, help="plan/batch_size (4 = plan_rbp_test.launch; 8 = BASELINE config C5)")
+    ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
+    ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,7 +122,7 @@ def main():
     from swarm_simulator_amd import _abi as A
     from swarm_simulator_amd.types import Param
 
-    param = Param.test_sweep()
+    param = Param.test_sweep(batch_size=args.batch_size, iteration=args.iteration, sequential=not args.joint)
     map_ids = shard_missions(args.missions_per_gpu, rank, world_size)
     mission, worlds, plans = build_inputs(map_ids, args.agents, param)
     K, N, M = len(plans), mission.qn, plans[0].M
@@ -170,7 +173,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pmc.get("missions_per_gpu") == K and N == 64:
+            if pmc.get("missions_per_gpu") == K and N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint:
                 traffic = pmc["kernels"]["qp_batch_kernel"]["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -180,8 +183,8 @@ def main():
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{N}-agent random_forest mission (mission_{N}agents_15.json) on worlds/map1..50.bt, {K} "
-                                   f"missions in flight per GPU ({K / 50:g} passes of the 50-map sweep), sequential=true "
-                                   f"batch_size=4 (plan_rbp_test.launch)",
+                                   f"missions in flight per GPU ({K / 50:g} passes of the 50-map sweep), sequential={str(not args.joint).lower()} "
+                                   f"batch_size={args.batch_size} iteration={args.iteration} (plan_rbp_test.launch keys)",
                        "agents": N, "segments": M, "missions_per_gpu": K, "parallelism": f"missions sharded over {world_size} GPU(s)",
                        "all_missions_ok": not any(status)},
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},

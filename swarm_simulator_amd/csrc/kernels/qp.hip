@@ -27,7 +27,7 @@
 #ifndef QP_THREADS
 #define QP_THREADS 512
 #endif
-#define QP_MAX_NB 8          // nk = 72: three (nk x (nk+1)) f64 blocks = 126 KB of LDS
+#define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
 #define QP_MAX_ITERS 80
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
 #define POLISH_LDS_DOUBLES (96 * 97 / 2 + 128 + 128 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
@@ -61,6 +61,7 @@ struct QpDims {
     int N, M, oq;       // agents, segments, 6M
     int nb, NF, npb;    // batch agents, frozen agents, in-batch pairs
     int nk, nj, ld;     // block order 9*nb, knots M-1, padded leading dimension
+    int ldb;            // leading dimension of the knot blocks in global memory: nk (wave path) or nk rounded up to 16 (tiled path)
     int first;          // first agent of the batch (batches are contiguous: qi / batch_size == l)
     size_t nbnd, nfro, npr, nrows;
 };
@@ -69,6 +70,7 @@ __host__ __device__ inline QpDims make_dims(int N, int M, int first, int nb) {
     QpDims d;
     d.N = N, d.M = M, d.oq = 6 * M, d.nb = nb, d.NF = N - nb, d.npb = nb * (nb - 1) / 2;
     d.nk = 9 * nb, d.nj = M - 1, d.ld = d.nk + 1, d.first = first;
+    d.ldb = d.nk <= 36 ? d.nk : ((d.nk + 15) & ~15);
     d.nbnd = (size_t)nb * 6 * d.oq, d.nfro = (size_t)nb * d.NF * d.oq, d.npr = (size_t)d.npb * d.oq;
     d.nrows = d.nbnd + d.nfro + d.npr;
     return d;
@@ -94,7 +96,8 @@ struct QpWs {
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
-               2 * (size_t)d.nj * d.nk + 3 * (size_t)d.nj * d.nk * d.nk + (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.nk * d.nk +
+               2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
+               (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2 +
                /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8) +
                /* row constants */ 4 * (size_t)nbmax * N * d.oq;
@@ -117,9 +120,10 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.cvec = p, p += (size_t)nbmax * 3 * d.oq;
     w.rbase = p, p += (size_t)dm.nj * dm.nk;
     w.rhs = p, p += (size_t)dm.nj * dm.nk;
-    w.Td = p, p += (size_t)dm.nj * dm.nk * dm.nk;
-    w.To = p, p += (size_t)(dm.nj > 1 ? dm.nj - 1 : 1) * dm.nk * dm.nk;
-    w.Lf = p, p += 2 * (size_t)dm.nj * dm.nk * dm.nk;
+    p += (4 - ((p - base) & 3)) & 3;  // 32-byte alignment of the blocks (vector loads of the tiled path)
+    w.Td = p, p += (size_t)dm.nj * dm.ldb * dm.ldb;
+    w.To = p, p += (size_t)(dm.nj > 1 ? dm.nj - 1 : 1) * dm.ldb * dm.ldb;
+    w.Lf = p, p += 2 * (size_t)dm.nj * (dm.nk < 36 ? dm.nk : 36) * (dm.nk < 36 ? dm.nk : 36);  // wave path only (a short last batch)
     w.boxlo = p, p += (size_t)nbmax * d.M * 3;
     w.boxhi = p, p += (size_t)nbmax * d.M * 3;
     w.Lk = p, p += (size_t)(d.M + 1) * 9;
@@ -492,12 +496,13 @@ __device__ void grad_ctrl(const RowCtx& c) {
         g *= 2 * sc;
         // G'z: own control-point accumulator + pair accumulators
         g += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];
-        int pr = 0;
-        for (int p = 0; p < d.nb; ++p)
-            for (int q = p + 1; q < d.nb; ++q, ++pr) {
-                if (p == a) g += w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
-                if (q == a) g -= w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
-            }
+        for (int o = 0; o < d.nb; ++o) {  // pairs (a,o): row = n.x_lo - n.x_hi
+            if (o == a) continue;
+            const int lo = a < o ? a : o, hi = a < o ? o : a;
+            const int pr = lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1);
+            const double v = w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
+            g += (a == lo) ? v : -v;
+        }
         w.cvec[it] = -g;
     }
 }
@@ -513,12 +518,13 @@ __device__ void gtv_ctrl(const RowCtx& c) {
             continue;
         }
         double g = w.cpacc[((size_t)a * oq + j6) * 12 + 6 + k];
-        int pr = 0;
-        for (int p = 0; p < d.nb; ++p)
-            for (int q = p + 1; q < d.nb; ++q, ++pr) {
-                if (p == a) g += w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
-                if (q == a) g -= w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
-            }
+        for (int o = 0; o < d.nb; ++o) {
+            if (o == a) continue;
+            const int lo = a < o ? a : o, hi = a < o ? o : a;
+            const int pr = lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1);
+            const double v = w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
+            g += (a == lo) ? v : -v;
+        }
         w.cvec[it] = g;
     }
 }
@@ -534,7 +540,7 @@ __device__ inline double sym3(const double* S, int k, int l) {
 __device__ void assemble_blocks(const RowCtx& c) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int nk = d.nk, oq = d.oq, nb = d.nb;
+    const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
     // work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out
     const int per_knot = nb * nb * 9;
     for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
@@ -547,10 +553,11 @@ __device__ void assemble_blocks(const RowCtx& c) {
             double sv;
             if (a == b) {
                 sv = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
-                int pr = 0;
-                for (int p1 = 0; p1 < nb; ++p1)
-                    for (int q1 = p1 + 1; q1 < nb; ++q1, ++pr)
-                        if (p1 == a || q1 == a) sv += sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+                for (int o = 0; o < nb; ++o) {
+                    if (o == a) continue;
+                    const int lo = a < o ? a : o, hi = a < o ? o : a;
+                    sv += sym3(w.pracc + ((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12, k, l);
+                }
             } else {
                 const int lo = a < b ? a : b, hi = a < b ? b : a;
                 const int pr = lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1);
@@ -559,7 +566,7 @@ __device__ void assemble_blocks(const RowCtx& c) {
             Sv[p] = sv;
         }
         const double* L = w.Lk + 9 * j;
-        double* out = w.Td + (size_t)(j - 1) * nk * nk + (size_t)(a * 9 + k * 3) * nk + b * 9 + l * 3;
+        double* out = w.Td + (size_t)(j - 1) * lb * lb + (size_t)(a * 9 + k * 3) * lb + b * 9 + l * 3;
 #pragma unroll
         for (int e = 0; e < 3; ++e)
 #pragma unroll
@@ -567,154 +574,20 @@ __device__ void assemble_blocks(const RowCtx& c) {
                 double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
                 if (e == f) acc += Sv[3 + e];
                 if (a == b && k == l) acc += w.Dk[9 * j + 3 * e + f];
-                out[(size_t)e * nk + f] = acc;
+                out[(size_t)e * lb + f] = acc;
             }
     }
     if (d.nj > 1) {
-        const size_t noff = (size_t)(d.nj - 1) * nk * nk;
+        const size_t noff = (size_t)(d.nj - 1) * lb * lb;
         for (size_t it = threadIdx.x; it < noff; it += QP_THREADS) {
-            const int j = (int)(it / ((size_t)nk * nk)) + 1;  // couples knot j (cols) and j+1 (rows)
-            const int rr = (int)(it % ((size_t)nk * nk)) / nk, cc = (int)(it % ((size_t)nk * nk)) % nk;
+            const int j = (int)(it / ((size_t)lb * lb)) + 1;  // couples knot j (cols) and j+1 (rows)
+            const int rr = (int)(it % ((size_t)lb * lb)) / lb, cc = (int)(it % ((size_t)lb * lb)) % lb;
             double v = 0;
-            if (rr / 3 == cc / 3) v = w.Ek[9 * j + 3 * (cc % 3) + (rr % 3)];  // E_j' : rows u_{j+1}, cols u_j
+            if (rr / 3 == cc / 3 && rr < nk && cc < nk) v = w.Ek[9 * j + 3 * (cc % 3) + (rr % 3)];  // E_j' : rows u_{j+1}, cols u_j
             w.To[it] = v;
         }
     }
 }
-
-// ------------------------------------------------------------------------------------------------------------
-// block-tridiagonal Cholesky, blocks staged in LDS (padded leading dimension ld = nk + 1)
-//   lds A : current diagonal block / its factor ;  lds B : L_{j,j-1} ;  lds C : T_{j+1,j} -> L_{j+1,j}
-// returns false if a pivot is not positive
-// ------------------------------------------------------------------------------------------------------------
-__device__ bool factor_blocks(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
-    const int nk = d.nk, ld = d.ld, tid = threadIdx.x;
-    if (tid == 0) *flag = 0;
-    __syncthreads();
-    for (int j = 0; j < d.nj; ++j) {
-        double* Dg = w.Td + (size_t)j * nk * nk;
-        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
-        if (j + 1 < d.nj) {
-            const double* Og = w.To + (size_t)j * nk * nk;
-            for (int it = tid; it < nk * nk; it += QP_THREADS) lC[(it / nk) * ld + it % nk] = Og[it];
-        }
-        __syncthreads();
-        if (j > 0) {  // A -= B B'
-            for (int it = tid; it < nk * nk; it += QP_THREADS) {
-                const int r = it / nk, cidx = it % nk;
-                if (cidx > r) continue;
-                double s = 0;
-                for (int k = 0; k < nk; ++k) s += lB[r * ld + k] * lB[cidx * ld + k];
-                lA[r * ld + cidx] -= s;
-            }
-            __syncthreads();
-        }
-        // Cholesky of A by wave 0 (left-looking, lanes over rows; nk <= 72 -> up to 2 rows per lane)
-        if (tid < 64) {
-            for (int cidx = 0; cidx < nk; ++cidx) {
-                for (int r = cidx + tid; r < nk; r += 64) {
-                    double s = lA[r * ld + cidx];
-                    for (int k = 0; k < cidx; ++k) s -= lA[r * ld + k] * lA[cidx * ld + k];
-                    lA[r * ld + cidx] = s;  // unscaled
-                }
-                __builtin_amdgcn_wave_barrier();
-                const double dd = lA[cidx * ld + cidx];
-                if (!(dd > 0)) {
-                    if (tid == 0) *flag = 1;
-                    break;
-                }
-                const double inv = 1.0 / sqrt(dd);
-                __builtin_amdgcn_wave_barrier();
-                for (int r = cidx + tid; r < nk; r += 64) lA[r * ld + cidx] *= inv;  // diag becomes sqrt(dd)
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-        if (*flag) return false;
-        // C <- C A^{-T}: each row of C independently (forward substitution along columns)
-        if (j + 1 < d.nj) {
-            for (int r = tid; r < nk; r += QP_THREADS) {
-                for (int cidx = 0; cidx < nk; ++cidx) {
-                    double s = lC[r * ld + cidx];
-                    for (int k = 0; k < cidx; ++k) s -= lC[r * ld + k] * lA[cidx * ld + k];
-                    lC[r * ld + cidx] = s / lA[cidx * ld + cidx];
-                }
-            }
-        }
-        __syncthreads();
-        for (int it = tid; it < nk * nk; it += QP_THREADS) Dg[it] = lA[(it / nk) * ld + it % nk];
-        if (j + 1 < d.nj) {
-            double* Og = w.To + (size_t)j * nk * nk;
-            for (int it = tid; it < nk * nk; it += QP_THREADS) {
-                const double v = lC[(it / nk) * ld + it % nk];
-                Og[it] = v;
-                lB[(it / nk) * ld + it % nk] = v;
-            }
-        }
-        __syncthreads();
-    }
-    return true;
-}
-
-// solve T du = rhs in place (rhs in global, one nk-vector per knot); lv = LDS scratch of 2*nk doubles.
-// The diagonal factor of each knot is staged into LDS (lA) before the substitution: the substitution is a chain
-// of nk dependent steps and must not pay a global-memory latency per step.
-__device__ void solve_blocks(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
-    const int nk = d.nk, ld = d.ld, tid = threadIdx.x;
-    double* cur = lv;
-    double* prev = lv + nk;
-    for (int j = 0; j < d.nj; ++j) {  // forward
-        const double* Dg = w.Td + (size_t)j * nk * nk;
-        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
-        for (int r = tid; r < nk; r += QP_THREADS) {
-            double s = rhs[(size_t)j * nk + r];
-            if (j > 0) {
-                const double* Lo = w.To + (size_t)(j - 1) * nk * nk + (size_t)r * nk;
-                for (int k = 0; k < nk; ++k) s -= Lo[k] * prev[k];
-            }
-            cur[r] = s;
-        }
-        __syncthreads();
-        if (tid < 64) {  // forward substitution with the diagonal factor, wave 0, column oriented
-            for (int cidx = 0; cidx < nk; ++cidx) {
-                const double xc = cur[cidx] / lA[cidx * ld + cidx];
-                __builtin_amdgcn_wave_barrier();
-                if (tid == 0) cur[cidx] = xc;
-                for (int r = cidx + 1 + tid; r < nk; r += 64) cur[r] -= lA[r * ld + cidx] * xc;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r], prev[r] = cur[r];
-        __syncthreads();
-    }
-    for (int j = d.nj - 1; j >= 0; --j) {  // backward
-        const double* Dg = w.Td + (size_t)j * nk * nk;
-        for (int it = tid; it < nk * nk; it += QP_THREADS) lA[(it / nk) * ld + it % nk] = Dg[it];
-        for (int cidx = tid; cidx < nk; cidx += QP_THREADS) {
-            double s = rhs[(size_t)j * nk + cidx];
-            if (j + 1 < d.nj) {
-                const double* Lo = w.To + (size_t)j * nk * nk;  // L_{j+1,j}
-                for (int a = 0; a < nk; ++a) s -= Lo[(size_t)a * nk + cidx] * prev[a];
-            }
-            cur[cidx] = s;
-        }
-        __syncthreads();
-        if (tid < 64) {  // back substitution with A' (row oriented on A)
-            for (int cidx = nk - 1; cidx >= 0; --cidx) {
-                const double xc = cur[cidx] / lA[cidx * ld + cidx];
-                __builtin_amdgcn_wave_barrier();
-                if (tid == 0) cur[cidx] = xc;
-                for (int k = tid; k < cidx; k += 64) cur[k] -= lA[cidx * ld + k] * xc;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __syncthreads();
-        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r], prev[r] = cur[r];
-        __syncthreads();
-    }
-}
-
 
 // ------------------------------------------------------------------------------------------------------------
 // wave-register path (nk <= 36, i.e. batches of up to 4 agents): the whole block-tridiagonal Cholesky and the
@@ -1082,6 +955,261 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// tiled path (nk > 36: batches of 5..64 agents, e.g. plan/batch_size = 8 or the joint QP of a whole mission).
+// Knot blocks live in global memory (L2-resident), row-major with the leading dimension ld = nk rounded up to 16
+// (padding rows/columns are identity), cut into 16x16 tiles for v_mfma_f64_16x16x4_f64:
+//   factor, per knot j, LEFT-looking over tile columns p of the stacked panel [A_j ; C_j]  (A_j = T_jj - B B',
+//   B = L_{j,j-1}, C_j = T_{j+1,j}):
+//     (1) tile (ti,p) -= B(ti,:) B(p,:)' + A(ti,:16p) A(p,:16p)'      (8 waves, one MFMA tile each, K = ld + 16p)
+//         C(ti,p)    -= C(ti,:16p) A(p,:16p)'
+//     (2) every wave factors the 16x16 diagonal tile in registers (lane = row, v_readlane broadcasts) and
+//     (3) solves its share of the rows below (one row per lane):  X <- X L_pp^{-T}
+//   two workgroup barriers per tile column.  L_jj overwrites the lower triangle of Td[j], L_{j+1,j} overwrites To[j].
+//   substitutions: block matvecs by the whole workgroup, the triangular solves by wave 0 tile by tile.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ d4 ld4(const double* p) { return *reinterpret_cast<const d4*>(p); }
+
+// acc += X(16 x K) Y(16 x K)'   (X, Y row-major, K a multiple of 16).  Lane (i = l&15, g = l>>4) loads X[i][k0+4g .. +3]:
+// the four MFMA steps of a 16-chunk use k = 4g + s on both operands, a permutation of the summation index.
+__device__ __forceinline__ void tile_nt(d4& acc, const double* X, int ldx, const double* Y, int ldy, int K, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const double* xp = X + (size_t)i * ldx + 4 * g;
+    const double* yp = Y + (size_t)i * ldy + 4 * g;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const d4 xa = ld4(xp + k0), yb = ld4(yp + k0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], yb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], yb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], yb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], yb[3], acc, 0, 0, 0);
+    }
+}
+
+// C(16x16) -= acc   (C/D layout: row = (l>>4) + 4*reg, col = l&15)
+__device__ __forceinline__ void tile_sub(double* C, int ldc, const d4& acc, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(size_t)(g + 4 * r) * ldc + i] -= acc[r];
+}
+
+__device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag) {
+    const int ld = d.ldb, NT = ld / 16, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = QP_THREADS / 64;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int j = 0; j < d.nj; ++j) {
+        double* A = w.Td + (size_t)j * ld * ld;
+        const double* B = j > 0 ? w.To + (size_t)(j - 1) * ld * ld : nullptr;
+        double* C = j + 1 < d.nj ? w.To + (size_t)j * ld * ld : nullptr;
+        for (int p = 0; p < NT; ++p) {
+            const int nA = NT - p, nC = (C && p > 0) ? NT : 0;
+            if (B || p > 0) {
+                for (int t = wave; t < nA + nC; t += NW) {
+                    d4 acc = d4{0, 0, 0, 0};
+                    const double* Ap = A + (size_t)p * 16 * ld;
+                    if (t < nA) {
+                        const int ti = p + t;
+                        if (B) tile_nt(acc, B + (size_t)ti * 16 * ld, ld, B + (size_t)p * 16 * ld, ld, ld, lane);
+                        if (p > 0) tile_nt(acc, A + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                        tile_sub(A + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
+                    } else {
+                        const int ti = t - nA;
+                        tile_nt(acc, C + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                        tile_sub(C + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            // diagonal tile: every wave factors its own register copy (lane&15 = row)
+            double a[16];
+            {
+                const double* dp = A + (size_t)(16 * p + (lane & 15)) * ld + 16 * p;
+                const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
+            }
+            const bool ok = chol_rows<16>(a);
+            if (!ok && tid == 0) *flag = 1;
+            // rows below in A, all rows of C:  x <- x L_pp^{-T}
+            const int nbelow = ld - 16 * (p + 1), total = nbelow + (C ? ld : 0);
+            for (int base = 0; base < total; base += QP_THREADS) {
+                const int idx = base + tid;
+                const bool act = idx < total;
+                double* rp = !act ? A : (idx < nbelow ? A + (size_t)(16 * (p + 1) + idx) * ld + 16 * p : C + (size_t)(idx - nbelow) * ld + 16 * p);
+                double x[16];
+                const d4 v0 = ld4(rp), v1 = ld4(rp + 4), v2 = ld4(rp + 8), v3 = ld4(rp + 12);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = v0[k], x[4 + k] = v1[k], x[8 + k] = v2[k], x[12 + k] = v3[k];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double sv = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) sv -= x[k] * rl(a[k], c);
+                    x[c] = sv / rl(a[c], c);
+                }
+                if (act) {
+                    *reinterpret_cast<d4*>(rp) = d4{x[0], x[1], x[2], x[3]};
+                    *reinterpret_cast<d4*>(rp + 4) = d4{x[4], x[5], x[6], x[7]};
+                    *reinterpret_cast<d4*>(rp + 8) = d4{x[8], x[9], x[10], x[11]};
+                    *reinterpret_cast<d4*>(rp + 12) = d4{x[12], x[13], x[14], x[15]};
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (*flag) return false;
+            if (wave == 0 && lane < 16) {  // nobody reads the diagonal tile again during the factorisation
+                double* dp = A + (size_t)(16 * p + lane) * ld + 16 * p;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dp[k] = k <= lane ? a[k] : 0.0;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    return true;
+}
+
+// v <- L^{-1} v for one knot block (wave 0; v in LDS, ld entries)
+__device__ __forceinline__ void trisolve_fwd(const double* L, int ld, double* v, int lane) {
+    const int NT = ld / 16, i = lane & 15;
+    for (int p = 0; p < NT; ++p) {
+        double a[16];
+        const double* dp = L + (size_t)(16 * p + i) * ld + 16 * p;
+        const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
+        double x = v[16 * p + i];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double xc = rl(x, c) / rl(a[c], c);
+            x = (i == c) ? xc : (i > c ? x - a[c] * xc : x);
+        }
+        if (lane < 16) v[16 * p + i] = x;
+        for (int r0 = 16 * (p + 1); r0 < ld; r0 += 64) {
+            const int r = r0 + lane;
+            const bool act = r < ld;
+            const double* rp = L + (size_t)(act ? r : 0) * ld + 16 * p;
+            const d4 u0 = ld4(rp), u1 = ld4(rp + 4), u2 = ld4(rp + 8), u3 = ld4(rp + 12);
+            double sv = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                sv += u0[k] * rl(x, k) + u1[k] * rl(x, 4 + k) + u2[k] * rl(x, 8 + k) + u3[k] * rl(x, 12 + k);
+            if (act) v[r] -= sv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// v <- L^{-T} v
+__device__ __forceinline__ void trisolve_bwd(const double* L, int ld, double* v, int lane) {
+    const int NT = ld / 16, i = lane & 15;
+    for (int p = NT - 1; p >= 0; --p) {
+        double at[16];  // column i of the diagonal tile
+#pragma unroll
+        for (int k = 0; k < 16; ++k) at[k] = L[(size_t)(16 * p + k) * ld + 16 * p + i];
+        double x = v[16 * p + i];
+#pragma unroll
+        for (int c = 15; c >= 0; --c) {
+            const double xc = rl(x, c) / rl(at[c], c);
+            x = (i == c) ? xc : (i < c ? x - at[c] * xc : x);
+        }
+        if (lane < 16) v[16 * p + i] = x;
+        for (int k0 = 0; k0 < 16 * p; k0 += 64) {
+            const int k = k0 + lane;
+            const bool act = k < 16 * p;
+            const double* cp = L + (size_t)(16 * p) * ld + (act ? k : 0);
+            double sv = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sv += cp[(size_t)c * ld] * rl(x, c);
+            if (act) v[k] -= sv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// solve T du = rhs in place (rhs in global, nk per knot).  lds: 2*ld vector buffers + QP_THREADS partial sums.
+__device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
+    const int nk = d.nk, ld = d.ldb, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* cur = lds;
+    double* oth = lds + ld;
+    double* part = lds + 2 * ld;
+    for (int j = 0; j < d.nj; ++j) {  // forward: v_j <- L_jj^{-1} (v_j - L_{j,j-1} v_{j-1})
+        for (int r = tid; r < ld; r += QP_THREADS) cur[r] = r < nk ? rhs[(size_t)j * nk + r] : 0.0;
+        __syncthreads();
+        if (j > 0) {
+            const double* Lo = w.To + (size_t)(j - 1) * ld * ld;
+            const int i = tid & 15;
+            for (int r0 = 0; r0 < nk; r0 += QP_THREADS / 16) {  // 16 lanes per row
+                const int r = r0 + (tid >> 4);
+                double sv = 0;
+                if (r < nk)
+                    for (int c = i; c < ld; c += 16) sv += Lo[(size_t)r * ld + c] * oth[c];
+                sv += __shfl_xor(sv, 8), sv += __shfl_xor(sv, 4), sv += __shfl_xor(sv, 2), sv += __shfl_xor(sv, 1);
+                if (r < nk && i == 0) cur[r] -= sv;
+            }
+            __syncthreads();
+        }
+        if (wave == 0) trisolve_fwd(w.Td + (size_t)j * ld * ld, ld, cur, lane);
+        __syncthreads();
+        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
+        double* t = cur;
+        cur = oth, oth = t;
+    }
+    __threadfence_block();
+    for (int j = d.nj - 1; j >= 0; --j) {  // backward: v_j <- L_jj^{-T} (v_j - L_{j+1,j}' v_{j+1})
+        __syncthreads();
+        for (int r = tid; r < ld; r += QP_THREADS) cur[r] = r < nk ? rhs[(size_t)j * nk + r] : 0.0;
+        __syncthreads();
+        if (j + 1 < d.nj) {
+            const double* Lo = w.To + (size_t)j * ld * ld;
+            if (ld <= QP_THREADS) {
+                const int ng = QP_THREADS / ld, c = tid % ld, g = tid / ld;
+                if (g < ng) {
+                    double sv = 0;
+                    for (int r = g; r < ld; r += ng) sv += Lo[(size_t)r * ld + c] * oth[r];
+                    part[tid] = sv;
+                }
+                __syncthreads();
+                if (tid < nk) {
+                    double sv = 0;
+                    for (int q = 0; q < ng; ++q) sv += part[q * ld + tid];
+                    cur[tid] -= sv;
+                }
+            } else {
+                for (int c = tid; c < nk; c += QP_THREADS) {
+                    double sv = 0;
+                    for (int r = 0; r < ld; ++r) sv += Lo[(size_t)r * ld + c] * oth[r];
+                    cur[c] -= sv;
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) trisolve_bwd(w.Td + (size_t)j * ld * ld, ld, cur, lane);
+        __syncthreads();
+        for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
+        double* t = cur;
+        cur = oth, oth = t;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// identity padding of the diagonal blocks (once per launch: the factorisation maps it onto itself)
+__device__ void init_block_pads(const QpDims& d, const QpWs& w) {
+    const int nk = d.nk, ld = d.ldb;
+    if (ld == nk) return;
+    const int npad = ld - nk;
+    for (int it = threadIdx.x; it < d.nj * npad * ld; it += QP_THREADS) {
+        const int j = it / (npad * ld), q = it % (npad * ld), r = nk + q / ld, c = q % ld;
+        double* A = w.Td + (size_t)j * ld * ld;
+        A[(size_t)r * ld + c] = r == c ? 1.0 : 0.0;
+        A[(size_t)c * ld + r] = r == c ? 1.0 : 0.0;
+    }
+}
+
 __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
     if (d.nk <= 36) {
         switch (d.nk) {
@@ -1091,7 +1219,7 @@ __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, doub
             default: return twisted_factor<36>(d, w, flag, lA);
         }
     }
-    return factor_blocks(d, w, lA, lB, lC, flag);
+    return factor_tiled(d, w, flag);
 }
 
 __device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
@@ -1104,7 +1232,7 @@ __device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, doub
         }
         return;
     }
-    solve_blocks(d, w, rhs, lv, lA);
+    solve_tiled(d, w, rhs, lA);
 }
 
 #define QP_POLISH_PART 2
@@ -1167,6 +1295,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     int* flag2 = flag;
 
     mission_constants(d, T, const_cast<QpWs&>(w));
+    init_block_pads(d, w);
 
     // SFC box of every (batch agent, segment): first box with end time >= T[m+1]  (rbp_planner.hpp:447-453)
     for (int a = tid; a < nb; a += QP_THREADS) {
@@ -1644,8 +1773,8 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             hipStreamSynchronize(st);
             return;
         }
-        const int nk = 9 * bs, ld = nk + 1;
-        size_t lds = sizeof(double) * ((size_t)3 * nk * ld + 2 * nk + 32) + 16;
+        const int nk = 9 * bs;
+        size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         if (nk <= 36) {
             lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 2 * 36 * 36 + 36 * 129 + 32) + 16);
             lds = std::max(lds, sizeof(double) * ((size_t)8 * nk * (nk + 1) + (size_t)(M - 1) * nk + 64));

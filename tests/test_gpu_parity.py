@@ -98,6 +98,28 @@ def test_wide_batches_vs_oracle(pkw):
     assert veq < FEAS_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
 
 
+@pytest.mark.parametrize("mission,pkw", [("mission_16agents_15.json", dict(sequential=False)),
+                                         ("mission_16agents_15.json", dict(batch_size=16, iteration=1)),
+                                         ("mission_64agents_15.json", dict(batch_size=12, batch_iter=2, iteration=1))])
+def test_very_wide_batches_vs_oracle(mission, pkw):
+    """batches of more than 8 agents (joint QP of a whole 16-agent mission, BASELINE.json C3-style; batches of 12):
+    block order 108/144 runs on the generic global-memory block path (no polish) -> interior-point tolerance."""
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission(mission)
+    w = host.load_world("map3.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    assert O.planner_update(m, p, ref)[0] == 0
+    assert planner.Corridor(w, m, p).update(False, gpu)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu), pl.last_error
+    assert np.abs(ref.ctrl - gpu.ctrl).max() < 5e-3
+    assert abs(ref.total_cost - gpu.total_cost) < 1e-4 * max(1.0, abs(ref.total_cost))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < FEAS_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
 def test_planner_only_call_with_host_corridor():
     """RBPPlanner::update as a drop-in on a PlanResult whose corridor came from elsewhere (here: the golden)."""
     c = Case("s8_map5_seq4")

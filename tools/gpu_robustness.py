@@ -1,0 +1,37 @@
+"""Developer tool: run many (mission, map) combinations on the GPU and report failures / polish rate."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param, PlanResult
+from tests import oracle_lib as O
+p = Param.test_sweep()
+for mf in sys.argv[1:]:
+    m = host.load_mission(mf)
+    worlds, plans = [], []
+    for i in range(1, 51, 3):
+        w = host.load_world(f"map{i}.bt", p)
+        try:
+            pr = host.ecbs_plan(w, m, p)
+        except RuntimeError as e:
+            continue
+        worlds.append(w); plans.append(pr)
+    M = max(q.M for q in plans)
+    pl2 = []
+    for q in plans:
+        pad = M - q.M
+        traj = np.concatenate([q.init_traj, np.repeat(q.init_traj[:, -1:, :], pad, axis=1)], axis=1)
+        T = np.concatenate([q.T, q.T[-1] + np.arange(1, pad + 1)])
+        pl2.append(PlanResult(traj, T))
+    s = planner.Session(worlds, [m] * len(pl2), p, pl2)
+    t = time.time(); s.run(); st = s.download(); dt = time.time() - t
+    sc = s.scalars()
+    worst = 0
+    for q in pl2:
+        if q.total_cost > 0:
+            obj, veq, vbox, vrs = O.evaluate_ctrl(m, q)
+            worst = max(worst, veq, vbox, vrs)
+    ratios = [host.validate(m, p, q)[0] for q, ok in zip(pl2, st) if ok == 0]
+    print(f"{mf}: missions {len(pl2)} failed {sum(1 for x in st if x)} status {sorted(set(st))} qps {sc[:,3].sum():.0f} polished {sc[:,4].sum():.0f} "
+          f"max violation {worst:.2e} min safety ratio {min(ratios) if ratios else None} time {dt:.2f}s")
+    s.close()
