@@ -1210,7 +1210,7 @@ __device__ void init_block_pads(const QpDims& d, const QpWs& w) {
     }
 }
 
-__device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, double* lB, double* lC, int* flag) {
+__device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag) {
     if (d.nk <= 36) {
         switch (d.nk) {
             case 9: return twisted_factor<9>(d, w, flag, lA);
@@ -1222,7 +1222,7 @@ __device__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, doub
     return factor_tiled(d, w, flag);
 }
 
-__device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lv, double* lA) {
+__device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA) {
     if (d.nk <= 36) {
         switch (d.nk) {  // lA = start of the dynamic LDS region (the three block buffers are free between factorisations)
             case 9: solve_staged<9>(d, w, rhs, lA); break;
@@ -1233,6 +1233,34 @@ __device__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, doub
         return;
     }
     solve_tiled(d, w, rhs, lA);
+}
+
+
+// The block factorisation / substitutions are compiled as stand-alone functions with by-value arguments: their register
+// allocation (the wave-register path wants every VGPR) then neither depends on nor disturbs the row sweeps around them,
+// and no kernel-level struct has its address taken.
+struct BlkArgs {
+    int nk, nj, ldb;
+    double *Td, *To, *Lf;
+    double* Ek;
+};
+__device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w) {
+    d = QpDims{};
+    w = QpWs{};
+    d.nk = b.nk, d.nj = b.nj, d.ldb = b.ldb, d.ld = b.nk + 1;
+    w.Td = b.Td, w.To = b.To, w.Lf = b.Lf, w.Ek = b.Ek;
+}
+__device__ __noinline__ bool factor_entry(BlkArgs b, double* lds, int* flag) {
+    QpDims d;
+    QpWs w;
+    blk_unpack(b, d, w);
+    return factor_dispatch(d, w, lds, flag);
+}
+__device__ __noinline__ void solve_entry(BlkArgs b, double* rhs, double* lds) {
+    QpDims d;
+    QpWs w;
+    blk_unpack(b, d, w);
+    solve_dispatch(d, w, rhs, lds);
 }
 
 #define QP_POLISH_PART 2
@@ -1260,7 +1288,7 @@ __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
 // ------------------------------------------------------------------------------------------------------------
 // one batch QP per workgroup
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int batch,
+__global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int batch,
                                                                int nbmax, int reset_cost) {
     const int mission = blockIdx.x, tid = threadIdx.x;
     if (S.status[mission] != 0) return;
@@ -1288,9 +1316,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
     int* flag = (int*)(lds_raw + 16);
     double* lds = lds_raw + 32;
     double* lA = lds;
-    double* lB = lA + (size_t)d.nk * d.ld;
-    double* lC = lB + (size_t)d.nk * d.ld;
-    double* lv = lC + (size_t)d.nk * d.ld;  // 2*nk
+    const BlkArgs ba{d.nk, d.nj, d.ldb, w.Td, w.To, w.Lf, w.Ek};
     double* red2 = red;
     int* flag2 = flag;
 
@@ -1452,7 +1478,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         PROF(3);
         __threadfence_block();
         __syncthreads();
-        if (!factor_dispatch(d, w, lA, lB, lC, flag)) break;
+        if (!factor_entry(ba, lA, flag)) break;
         flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
         PROF(4);
         // ---- predictor
@@ -1466,7 +1492,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         __threadfence_block();
         __syncthreads();
         PROF(5);
-        solve_dispatch(d, w, w.rhs, lv, lA);
+        solve_entry(ba, w.rhs, lA);
         PROF(6);
         apply_F(d, w, w.rhs, w.dxa);
         __threadfence_block();
@@ -1498,7 +1524,7 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         __threadfence_block();
         __syncthreads();
         PROF(5);
-        solve_dispatch(d, w, w.rhs, lv, lA);
+        solve_entry(ba, w.rhs, lA);
         PROF(6);
         apply_F(d, w, w.rhs, w.dx);
         __threadfence_block();
@@ -1537,22 +1563,15 @@ __global__ __launch_bounds__(QP_THREADS) void qp_batch_kernel(DevSession S, doub
         if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
         return;
     }
-    // ---- active-set polish (nk <= 36 path)
+    // ---- active-set polish
     int polished = 0;
-    if (d.nk <= 36 && S.p.polish) {
+    if (S.p.polish) {
         PolishWs pw;
         pw.cand = (Cand*)w.polish;
         pw.V = w.polish + 128 * 14;
         pw.Sg = pw.V + (size_t)129 * d.nj * d.nk;
         pw.ncand = (int*)(pw.Sg + 128 * 128);
-        c.pw = &pw;
-        int acc = 0;
-        switch (d.nk) {
-            case 9: acc = polish_qp<9>(c, io, pw, lds, red2, flag2); break;
-            case 18: acc = polish_qp<18>(c, io, pw, lds, red2, flag2); break;
-            case 27: acc = polish_qp<27>(c, io, pw, lds, red2, flag2); break;
-            default: acc = polish_qp<36>(c, io, pw, lds, red2, flag2); break;
-        }
+        const int acc = polish_entry(c, pw, lds, red2, flag2);
         polished = acc == 0 ? 1 : 0;
         PROF(0);
         if (acc != 0 && tid == 0) scal[7] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
@@ -1774,11 +1793,13 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             return;
         }
         const int nk = 9 * bs;
+        // dynamic LDS: the largest of the tiled path's vectors, the polish (dual factor + 3x3 chain factor) and the
+        // wave path's staged substitutions (a short last batch may take the wave path even when bs > 4)
+        const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
-        if (nk <= 36) {
-            lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 2 * 36 * 36 + 36 * 129 + 32) + 16);
-            lds = std::max(lds, sizeof(double) * ((size_t)8 * nk * (nk + 1) + (size_t)(M - 1) * nk + 64));
-        }
+        lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 18 * (M - 1) + 32) + 16);
+        lds = std::max(lds, sizeof(double) * ((size_t)8 * nkw * (nkw + 1) + (size_t)(M - 1) * nkw + 64));
+        lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
         hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
             for (int l = 0; l < biter; ++l)

@@ -6,8 +6,9 @@ import bench
 from swarm_simulator_amd import planner, _abi as A
 from swarm_simulator_amd.types import Param
 K = int(os.environ.get("K", "4"))
-p = Param.test_sweep()
-m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), 64, p)
+p = Param.test_sweep(batch_size=int(os.environ.get("BS", "4")), iteration=int(os.environ.get("ITER", "1")), sequential=os.environ.get("JOINT", "0") != "1")
+NA = int(os.environ.get("AGENTS", "64"))
+m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), NA, p)
 s = planner.Session(worlds, [m] * K, p, plans)
 s.run(); st = s.download()
 sc = s.scalars()
@@ -17,3 +18,5 @@ print("status", st, "iters", sc[:, 2])
 for i, n in enumerate(names):
     print(f"{n:18s} {sc[:, 8 + i].mean() / 1e8 * 1e3:9.2f} ms (100 MHz clock)  {100 * sc[:, 8 + i].sum() / tot.sum():5.1f} %")
 print("total", tot.mean() / 1e8 * 1e3, "ms per mission")
+for i, n in enumerate(["polish: candidates+K0+gradient", "polish: V columns + S", "polish: dual active-set (wave 0)", "polish: primal step/verify"]):
+    print(f"  {n:34s} {sc[:, 20 + i].mean() / 1e8 * 1e3:9.2f} ms")
