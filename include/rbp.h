@@ -119,6 +119,15 @@ typedef struct rbp_plan {
  * outputs are overwritten. */
 int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
 
+/* Agent-sharded Corridor::update for ONE large mission spread over several GPUs (one process per GPU): computes the SFC
+ * of agents qi in [agent_begin, agent_end) (the loop body of updateObsBox, rbp_corridor.hpp:154-239) and the RSFC rows
+ * of the pairs (qi, qj), qi < qj, with qi in that range (updateRelBox, :342-392); rsfc_time is written by every shard.
+ * All other entries of plan.{sfc_*, rsfc_normal} are unspecified: the caller exchanges the shards (all-gather over
+ * RCCL/xGMI, swarm_simulator_amd/sharded.py) and obtains exactly what rbp_corridor_update would have written.  Runs on
+ * the calling thread's current HIP device. */
+int rbp_corridor_update_range(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan,
+                              int32_t agent_begin, int32_t agent_end);
+
 /* RBPPlanner::update: reads mission, param, plan.{T,init_traj,sfc_*,rsfc_*}; writes plan.{coef,ctrl,
  * time_scale,total_cost,*_size} and rescales T / sfc_time / rsfc_time when time_scale != 1. */
 int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
@@ -135,6 +144,9 @@ enum { RBP_STAGE_CORRIDOR = 1, RBP_STAGE_PLANNER = 2, RBP_STAGE_ALL = 3 };
 int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
                        const rbp_param* param, const rbp_plan* plans);
 int rbp_session_run(rbp_session* s, int stages, void* stream);
+/* restrict the CORRIDOR stage of later `run` calls to agents / pair rows [agent_begin, agent_end) (see
+ * rbp_corridor_update_range); [0, N) restores the whole mission */
+int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t agent_end);
 /* blocks on `stream`, copies outputs into plans[0..K-1]; returns the first non-zero per-mission status
  * and, if `status` != NULL, every mission's status in status[0..K-1]. */
 int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream);

@@ -134,6 +134,7 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     }
     DevSession& d = s->d;
     d.K = K, d.N = N, d.M = M, d.max_boxes = MB, d.npair = npair;
+    d.agent_begin = 0, d.agent_end = N;
     for (int a = 0; a < 3; ++a) d.p.world_min[a] = param->world_min[a], d.p.world_max[a] = param->world_max[a];
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
@@ -242,6 +243,13 @@ int rbp_session_reset(rbp_session* s, void* stream) {
     return RBP_OK;
 }
 
+int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t agent_end) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (agent_begin < 0 || agent_end < agent_begin || agent_end > s->d.N) return fail(RBP_ERR_BAD_ARGUMENT, "agent range outside [0, N]");
+    s->d.agent_begin = agent_begin, s->d.agent_end = agent_end;
+    return RBP_OK;
+}
+
 int rbp_session_run(rbp_session* s, int stages, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     hipStream_t st = (hipStream_t)stream;
@@ -342,7 +350,8 @@ void rbp_session_destroy(rbp_session* s) {
     delete s;
 }
 
-static int one_shot(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan, int stages) {
+static int one_shot(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan, int stages,
+                    int agent_begin = 0, int agent_end = -1) {
     if (!mission || !param || !plan) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
     rbp_world dummy_world;
     float zero = 0.0f;
@@ -353,9 +362,12 @@ static int one_shot(const rbp_world* world, const rbp_mission* mission, const rb
         world = &dummy_world;
     }
     rbp_session* s = nullptr;
-    int rc = rbp_session_create(&s, 0, 1, world, mission, param, plan);
+    int dev = 0;
+    (void)hipGetDevice(&dev);  // the calling thread's current device (one process per GPU sets it once)
+    int rc = rbp_session_create(&s, dev, 1, world, mission, param, plan);
     if (rc) return rc;
-    rc = rbp_session_run(s, stages, nullptr);
+    if (agent_end >= 0) rc = rbp_session_set_agent_range(s, agent_begin, agent_end);
+    if (!rc) rc = rbp_session_run(s, stages, nullptr);
     if (!rc) {
         int32_t st = 0;
         rc = rbp_session_download(s, plan, &st, nullptr);
@@ -367,6 +379,13 @@ static int one_shot(const rbp_world* world, const rbp_mission* mission, const rb
 int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
     if (!world) return fail(RBP_ERR_BAD_ARGUMENT, "null world");
     return one_shot(world, mission, param, plan, RBP_STAGE_CORRIDOR);
+}
+
+int rbp_corridor_update_range(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan,
+                              int32_t agent_begin, int32_t agent_end) {
+    if (!world) return fail(RBP_ERR_BAD_ARGUMENT, "null world");
+    if (agent_end < 0) return fail(RBP_ERR_BAD_ARGUMENT, "agent range outside [0, N]");
+    return one_shot(world, mission, param, plan, RBP_STAGE_CORRIDOR, agent_begin, agent_end);
 }
 
 int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {

@@ -165,9 +165,9 @@ __device__ void expand_box(SfcCtx& c, double* box, int lane) {
 }
 
 __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
-    const int groups = (s.N + SFC_WAVES - 1) / SFC_WAVES;
+    const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
     const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qi = (blockIdx.x % groups) * SFC_WAVES + wave;
+    const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
     const int M = s.M, P = M + 1, MB = s.max_boxes;
     __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
     __shared__ unsigned mask[SFC_MASK_WORDS];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     // ---- occupancy bitmask of this mission's grid for the radius of the group's first agent, built once per workgroup
     // with coalesced reads + ballots.  The SFC test only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per
     // cell (29 KB for the 101x101x23 grid) replaces ~0.6 M float reads per agent from L2/MALL by LDS reads.
-    const int q0 = (blockIdx.x % groups) * SFC_WAVES;
+    const int q0 = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES;
     const double radius0 = s.radius[(size_t)mission * s.N + q0];
     const unsigned ncell = (unsigned)w.dim[0] * w.dim[1] * w.dim[2];
     const bool mask_fits = ncell + 64 <= 32u * SFC_MASK_WORDS;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
         }
     }
     __syncthreads();
-    if (qi >= s.N) return;
+    if (qi >= s.agent_end) return;
     SfcCtx c;
     c.grid = w.dist;
     c.rf = 1.0 / w.res;
@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
     int qi = 0, rem = pair;
     while (rem >= N - 1 - qi) rem -= N - 1 - qi, qi++;
     const int qj = qi + 1 + rem;
+    if (pair == 0) s.rsfc_time[(size_t)mission * M + seg] = s.T[(size_t)mission * P + seg + 1];  // :390 (every shard)
+    if (qi < s.agent_begin || qi >= s.agent_end) return;  // pair rows of another shard
     const float* ti = s.init_traj + ((size_t)mission * N + qi) * P * 3 + 3 * seg;
     const float* tj = s.init_traj + ((size_t)mission * N + qj) * P * 3 + 3 * seg;
     const double dw = s.p.downwash;
@@ -358,7 +360,6 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
     float* out = s.rsfc_normal + (((size_t)mission * s.npair + pair) * M + seg) * 3;
     out[0] = m[0], out[1] = m[1], out[2] = m[2];
     if (v_norm(m) == 0) atomicCAS(&s.status[mission], 0, (int)RBP_ERR_INIT_TRAJ_COLLIDE);  // :385-388
-    if (pair == 0) s.rsfc_time[(size_t)mission * M + seg] = s.T[(size_t)mission * P + seg + 1];  // :390
 }
 
 }  // namespace
@@ -367,9 +368,9 @@ void launch_corridor(const DevSession& s, hipStream_t st) {
     // updateObsBox() && updateRelBox() (:25): RSFC results are only meaningful if SFC succeeded; status keeps the
     // first error, with SFC errors taking precedence because sfc_kernel is enqueued first.
     const size_t lds = sizeof(int) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1);
-    const int groups = (s.N + SFC_WAVES - 1) / SFC_WAVES;
-    hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
+    const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
+    (void)hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (groups > 0) hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
     const long long total = (long long)s.K * s.npair * s.M;
     if (total > 0) hipLaunchKernelGGL(rsfc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s);
 }

@@ -1788,8 +1788,8 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
             // nk > 72 needs the tiled multi-workgroup factorisation (joint mode with N > 8): not in this round.
             // Fail loudly: every mission gets RBP_ERR_BAD_ARGUMENT.
             std::vector<int> bad(s.K, (int)RBP_ERR_BAD_ARGUMENT);
-            hipMemcpyAsync(s.status, bad.data(), sizeof(int) * s.K, hipMemcpyHostToDevice, st);
-            hipStreamSynchronize(st);
+            (void)hipMemcpyAsync(s.status, bad.data(), sizeof(int) * s.K, hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);
             return;
         }
         const int nk = 9 * bs;
@@ -1800,7 +1800,7 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 18 * (M - 1) + 32) + 16);
         lds = std::max(lds, sizeof(double) * ((size_t)8 * nkw * (nkw + 1) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
-        hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int iter = 0; iter < s.p.iteration; ++iter)
             for (int l = 0; l < biter; ++l)
                 hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,

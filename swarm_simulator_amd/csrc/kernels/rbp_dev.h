@@ -34,6 +34,7 @@ struct DevParam {
 // per-session pointers handed to kernels by value
 struct DevSession {
     int K, N, M, max_boxes, npair;
+    int agent_begin, agent_end;  // corridor stage only: agents (and pair rows i) of this shard, [0, N) when not sharded
     DevParam p;
     const DevWorld* worlds;   // [K]
     const float* init_traj;   // [K][N][M+1][3]

@@ -47,7 +47,9 @@ def lib():
         L.rbp_param_defaults.argtypes = [P(A.rbp_param)]
         L.rbp_param_defaults.restype = None
         L.rbp_corridor_update.argtypes = [P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_corridor_update_range.argtypes = [P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan), C.c_int32, C.c_int32]
         L.rbp_planner_update.argtypes = [P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_session_set_agent_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.rbp_session_create.argtypes = [P(C.c_void_p), C.c_int, C.c_int, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param),
                                          P(A.rbp_plan)]
         L.rbp_session_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -62,7 +64,8 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "rbp_param_defaults", "rbp_corridor_update", "rbp_planner_update", "rbp_session_create", "rbp_session_run",
+    "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
+    "rbp_session_run", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
     "rbp_version",
     "rbp_last_error", "rbp_device_count",
@@ -84,6 +87,14 @@ class Corridor:
     def update(self, log: bool, plan: PlanResult) -> bool:
         w, m, p, pl = self.world.c_struct(), self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
         self.rc = lib().rbp_corridor_update(C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
+        self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
+        return self.rc == 0
+
+    def update_range(self, plan: PlanResult, agent_begin: int, agent_end: int) -> bool:
+        """one shard of an agent-sharded update (include/rbp.h rbp_corridor_update_range): only the SFC of agents
+        [agent_begin, agent_end) and the RSFC rows of pairs (qi, qj) with qi in that range are valid afterwards."""
+        w, m, p, pl = self.world.c_struct(), self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
+        self.rc = lib().rbp_corridor_update_range(C.byref(w), C.byref(m), C.byref(p), C.byref(pl), agent_begin, agent_end)
         self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
         return self.rc == 0
 
@@ -125,6 +136,11 @@ class Session:
         rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))
         if rc:
             raise RuntimeError(f"rbp_session_run rc={rc}: {last_error()}")
+
+    def set_agent_range(self, agent_begin: int, agent_end: int):
+        rc = lib().rbp_session_set_agent_range(self._h, agent_begin, agent_end)
+        if rc:
+            raise RuntimeError(f"rbp_session_set_agent_range rc={rc}: {last_error()}")
 
     def reset(self, stream=None):
         rc = lib().rbp_session_reset(self._h, C.c_void_p(stream or 0))

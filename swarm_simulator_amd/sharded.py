@@ -1,0 +1,111 @@
+"""Agent-sharded plan step for ONE large mission on several GPUs (BASELINE.json config C4).
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+What shards, and what does not:
+  * Corridor::update shards by agent.  SFC boxes are independent per agent (rbp_corridor.hpp:154), RSFC rows are
+    independent per pair and only read the two agents' waypoints (:342-392).  Rank r computes the agents of its
+    contiguous slice and the pair rows (qi, qj) whose qi lies in the slice; ONE all-gather per array then gives every
+    rank the complete corridor, bit-identical to the unsharded call (the exchange moves bytes, never adds floats).
+  * RBPPlanner::update in the reference schedule (sequential=true) is a Gauss-Seidel sweep: batch l is solved against
+    the answers of batches < l (rbp_planner.hpp:140-203), so inside one mission it is serial by construction.  Every rank
+    therefore runs the same QP sweep on the gathered corridor (replicas: same code, same inputs, same bits) and no
+    further exchange is needed; scale-out of the QP comes from sharding MISSIONS (bench.py).  A Jacobi sweep over
+    ranks would parallelise it but is a different algorithm with different answers (both agents of a frozen pair move
+    at once, so the half-space rows no longer guarantee separation) and is deliberately not offered.
+"""
+import numpy as np
+
+from . import planner
+from .types import Mission, Param, PlanResult, World
+
+
+def agent_slices(n_agents: int, world_size: int):
+    """contiguous agent ranges [begin, end) per rank, as even as possible (the SFC growth, ~0.5 M distance samples per
+    agent, is the expensive part; the RSFC rows an agent owns are a few flops each); every agent belongs to one rank."""
+    base, extra = divmod(n_agents, world_size)
+    cuts = [0]
+    for r in range(world_size):
+        cuts.append(cuts[-1] + base + (1 if r < extra else 0))
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def pair_offset(n_agents: int, qi: int) -> int:
+    """index of pair (qi, qi+1) in the qi-major upper-triangular order of RSFC (rbp_corridor.hpp:342-344)."""
+    return qi * n_agents - qi * (qi + 1) // 2
+
+
+def _all_gather_ragged(dist, dev, local: np.ndarray, counts):
+    """all-gather of byte blocks of different lengths: pad to the longest, one all_gather, cut.  Bytes only: exact."""
+    import torch
+    world = len(counts)
+    maxb = max(max(counts), 1)
+    buf = np.zeros(maxb, dtype=np.uint8)
+    raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
+    assert raw.size == counts[dist.get_rank()]
+    buf[:raw.size] = raw
+    t = torch.from_numpy(buf).to(dev)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [o.cpu().numpy()[:counts[r]] for r, o in enumerate(outs)]
+
+
+def gather_corridor(dist, plan: PlanResult, n_agents: int, slices, dev="cpu"):
+    """exchange the shards written by rbp_corridor_update_range so that `plan` holds the whole corridor on every rank."""
+    rank = dist.get_rank()
+    M, MB = plan.M, plan.sfc_box.shape[1]
+    b, e = slices[rank]
+    # per-agent arrays: sfc_count [N] i32, sfc_box [N][MB][6] f64, sfc_time [N][MB] f64
+    for arr, per_agent in ((plan.sfc_count, 4), (plan.sfc_box, MB * 6 * 8), (plan.sfc_time, MB * 8)):
+        counts = [(se - sb) * per_agent for sb, se in slices]
+        parts = _all_gather_ragged(dist, dev, arr[b:e], counts)
+        flat = arr.view(np.uint8).reshape(-1)
+        for (sb, se), part in zip(slices, parts):
+            flat[sb * per_agent:se * per_agent] = part
+    # pair rows: rsfc_normal [npair][M][3] f32, rows of qi in [b, e) are contiguous
+    row = M * 3 * 4
+    offs = [(pair_offset(n_agents, sb), pair_offset(n_agents, se)) for sb, se in slices]
+    counts = [(o1 - o0) * row for o0, o1 in offs]
+    parts = _all_gather_ragged(dist, dev, plan.rsfc_normal[offs[rank][0]:offs[rank][1]], counts)
+    flat = plan.rsfc_normal.view(np.uint8).reshape(-1)
+    for (o0, o1), part in zip(offs, parts):
+        flat[o0 * row:o1 * row] = part
+
+
+class ShardedCorridor:
+    """Corridor::update for one mission whose agents are spread over the ranks of `dist` (None = single process)."""
+
+    def __init__(self, world: World, mission: Mission, param: Param, dist=None, device="cpu", compute=None):
+        self.world, self.mission, self.param, self.dist, self.device = world, mission, param, dist, device
+        self.last_error = ""
+        # compute(plan, begin, end) -> bool: the shard kernel.  Default: the HIP path through the C ABI.
+        self._cor = planner.Corridor(world, mission, param) if compute is None else None
+        self._compute = compute or (lambda plan, b, e: self._cor.update_range(plan, b, e))
+
+    def update(self, log: bool, plan: PlanResult) -> bool:
+        import torch
+        n = self.mission.qn
+        ws = 1 if self.dist is None else self.dist.get_world_size()
+        rank = 0 if self.dist is None else self.dist.get_rank()
+        slices = agent_slices(n, ws)
+        ok = bool(self._compute(plan, *slices[rank]))
+        if self._cor is not None:
+            self.last_error = self._cor.last_error
+        if self.dist is not None:
+            flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=self.device)
+            self.dist.all_reduce(flag)  # Corridor::update returns false if any agent / pair failed
+            ok = int(flag.item()) == 0
+            if ok:
+                gather_corridor(self.dist, plan, n, slices, self.device)
+        return ok
+
+
+def plan_sharded(world: World, mission: Mission, param: Param, plan: PlanResult, dist=None, device="cpu"):
+    """Corridor (agent-sharded + all-gather) then RBPPlanner (replicated sweep) for one mission; every rank returns with
+    the complete PlanResult.  Returns (ok, error text)."""
+    cor = ShardedCorridor(world, mission, param, dist, device)
+    if not cor.update(False, plan):
+        return False, cor.last_error or "corridor failed on another rank"
+    pl = planner.RBPPlanner(mission, param)
+    ok = pl.update(False, plan)
+    return ok, pl.last_error

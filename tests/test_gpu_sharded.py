@@ -1,0 +1,52 @@
+"""GPU: agent-sharded Corridor::update (rbp_corridor_update_range) and the 256-agent config C4 on one GPU."""
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.sharded import agent_slices, pair_offset, plan_sharded
+from swarm_simulator_amd.types import Param
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+C4_PARAM = dict(world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_range_shards_tile_the_full_corridor(n_shards):
+    """every shard call writes exactly its agents / pair rows, bit-identical to the unsharded call"""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_16agents_15.json")
+    w = host.load_world("map12.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    full = init.clone_inputs()
+    cor = planner.Corridor(w, m, p)
+    assert cor.update(False, full), cor.last_error
+    for b, e in agent_slices(m.qn, n_shards):
+        part = init.clone_inputs()
+        assert cor.update_range(part, b, e), cor.last_error
+        assert np.array_equal(part.sfc_count[b:e], full.sfc_count[b:e])
+        assert np.array_equal(part.sfc_box[b:e], full.sfc_box[b:e]) and np.array_equal(part.sfc_time[b:e], full.sfc_time[b:e])
+        o0, o1 = pair_offset(m.qn, b), pair_offset(m.qn, e)
+        assert np.array_equal(part.rsfc_normal[o0:o1].view(np.uint32), full.rsfc_normal[o0:o1].view(np.uint32))
+        assert np.array_equal(part.rsfc_time, full.rsfc_time)
+    assert not cor.update_range(init.clone_inputs(), 3, 99)  # outside [0, N]: refused
+
+
+def test_c4_256_agents_single_rank():
+    """config C4 (256 agents, tools/make_mission_256.py) through plan_sharded with one rank: corridor bit-exact against the
+    CPU checker, the QP sweep (64 batches, 252 frozen neighbours each) feasible and all equalities met."""
+    p = Param.test_sweep(**C4_PARAM)
+    m = host.load_mission("mission_256agents_c4.json")
+    assert m.qn == 256
+    w = host.load_world("map1.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    ok, err = plan_sharded(w, m, p, gpu)
+    assert ok, err
+    assert np.array_equal(ref.sfc_count, gpu.sfc_count) and np.array_equal(ref.sfc_box, gpu.sfc_box)
+    assert np.array_equal(ref.rsfc_normal.view(np.uint32), gpu.rsfc_normal.view(np.uint32))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < 1e-8 and vbox < 1e-8 and vrs < 1e-8
+    assert abs(obj - gpu.total_cost) < 1e-6 * max(1.0, obj)

@@ -42,3 +42,63 @@ def test_two_rank_gloo_aggregate(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n"] == 2 * 5 * 64 and res["t"] == 2.0 and res["maps"] == [1, 2, 3, 4, 5]
+
+
+def test_agent_slices_partition():
+    from swarm_simulator_amd.sharded import agent_slices, pair_offset
+    for n in (1, 4, 5, 16, 64, 256):
+        for ws in (1, 2, 3, 8):
+            sl = agent_slices(n, ws)
+            assert sl[0][0] == 0 and sl[-1][1] == n and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert max(e - b for b, e in sl) - min(e - b for b, e in sl) <= 1
+            # pair rows of the slices tile the upper triangle
+            assert sum(pair_offset(n, e) - pair_offset(n, b) for b, e in sl) == n * (n - 1) // 2
+
+
+def test_two_rank_gloo_sharded_corridor(tmp_path):
+    """agent-sharded Corridor::update (BASELINE config C4 path) with 2 gloo ranks: each rank fills ONLY its shard (the CPU
+    checker stands in for the HIP shard kernel, everything else is poisoned), the all-gather must reproduce the unsharded
+    corridor bit for bit, including the sign of zero normals."""
+    script = tmp_path / "s.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, json
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        import torch.distributed as dist
+        from swarm_simulator_amd import host
+        from swarm_simulator_amd.types import Param
+        from swarm_simulator_amd.sharded import ShardedCorridor, pair_offset
+        from tests import oracle_lib as O
+        dist.init_process_group("gloo")
+        p = Param.test_sweep()
+        m = host.load_mission("mission_16agents_15.json")
+        w = host.load_world("map7.bt", p)
+        init = host.ecbs_plan(w, m, p)
+        full = init.clone_inputs()
+        assert O.corridor_update(w, m, p, full)[0] == 0
+        full.rsfc_normal[0, 0, 2] = -0.0            # a signed zero must survive the exchange
+        def shard_kernel(plan, b, e):               # writes agents [b, e) and their pair rows only
+            plan.sfc_count[:] = -7; plan.sfc_box[:] = np.nan; plan.sfc_time[:] = np.nan; plan.rsfc_normal[:] = np.nan
+            plan.sfc_count[b:e] = full.sfc_count[b:e]; plan.sfc_box[b:e] = full.sfc_box[b:e]; plan.sfc_time[b:e] = full.sfc_time[b:e]
+            o0, o1 = pair_offset(m.qn, b), pair_offset(m.qn, e)
+            plan.rsfc_normal[o0:o1] = full.rsfc_normal[o0:o1]
+            plan.rsfc_time[:] = full.rsfc_time
+            return True
+        mine = init.clone_inputs()
+        ok = ShardedCorridor(w, m, p, dist, "cpu", compute=shard_kernel).update(False, mine)
+        same = (ok and np.array_equal(mine.sfc_count, full.sfc_count) and np.array_equal(mine.sfc_box, full.sfc_box)
+                and np.array_equal(mine.sfc_time, full.sfc_time)
+                and np.array_equal(mine.rsfc_normal.view(np.uint32), full.rsfc_normal.view(np.uint32)))
+        # a failing shard makes Corridor::update false on every rank
+        bad = ShardedCorridor(w, m, p, dist, "cpu", compute=lambda pl, b, e: dist.get_rank() != 1).update(False, init.clone_inputs())
+        print(json.dumps({{"rank": dist.get_rank(), "same": bool(same), "bad": bool(bad)}}))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(res) == 2 and all(r["same"] and not r["bad"] for r in res), res
