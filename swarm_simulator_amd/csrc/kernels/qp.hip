@@ -1286,10 +1286,10 @@ __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// one batch QP per workgroup
+// one batch QP of one mission (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int batch,
-                                                               int nbmax, int reset_cost) {
+__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int batch, int nbmax,
+                                              int reset_cost) {
     const int mission = blockIdx.x, tid = threadIdx.x;
     if (S.status[mission] != 0) return;
     const int N = S.N, M = S.M;
@@ -1601,6 +1601,20 @@ __global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(
     PROF_FLUSH(scal);
 }
 
+// One workgroup per mission runs the WHOLE Gauss-Seidel schedule of solveQP (rbp_planner.hpp:140-203: `passes` sweeps
+// over `biter` batches) in one launch: missions are independent, so nothing forces them to wait for each other at batch
+// boundaries (a launch per batch costs the sum over batches of the slowest mission's interior-point iteration count),
+// and with more missions than CUs the hardware dispatcher balances them.
+__global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int passes,
+                                                               int biter, int nbmax) {
+    for (int it = 0; it < passes; ++it)
+        for (int l = 0; l < biter; ++l) {
+            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0));
+            __threadfence_block();
+            __syncthreads();
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // epilogue: Bernstein -> monomial (rbp_planner.hpp:170-196), timeScale (:209-266)
 // ------------------------------------------------------------------------------------------------------------
@@ -1801,10 +1815,9 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         lds = std::max(lds, sizeof(double) * ((size_t)8 * nkw * (nkw + 1) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        for (int iter = 0; iter < s.p.iteration; ++iter)
-            for (int l = 0; l < biter; ++l)
-                hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
-                                   ws_bytes_per_mission / sizeof(double), l, bs, (int)(l == 0));
+        if (s.p.iteration > 0)
+            hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
+                               ws_bytes_per_mission / sizeof(double), s.p.iteration, biter, bs);
     }
     const size_t tot2 = (size_t)s.K * N * 3 * M;
     hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
