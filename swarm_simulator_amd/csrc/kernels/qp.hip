@@ -29,8 +29,14 @@
 #endif
 #define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
 #define QP_MAX_ITERS 80
+#ifndef QP_EARLY_TOL
+#define QP_EARLY_TOL 1e-5
+#endif
+#ifndef QP_EARLY_POLISH
+#define QP_EARLY_POLISH 1  // try the active-set polish before the interior-point loop has fully converged
+#endif
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
-#define POLISH_LDS_DOUBLES (96 * 97 / 2 + 128 + 128 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
+#define POLISH_LDS_DOUBLES (96 * 97 / 2 + 128 + 128 + 96 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
 
 namespace {
 
@@ -246,6 +252,7 @@ struct RowCtx {
     const PolishWs* pw;
     const DevSession* S;
     int mission;
+    int lds_avail;  // doubles of dynamic LDS behind the work-area pointer handed to the phases
     QpDims d;
     QpWs w;
     const double* ctrl;  // [N][3][oq] of this mission
@@ -1289,7 +1296,7 @@ __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
 // one batch QP of one mission (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int batch, int nbmax,
-                                              int reset_cost) {
+                                              int reset_cost, int lds_doubles) {
     const int mission = blockIdx.x, tid = threadIdx.x;
     if (S.status[mission] != 0) return;
     const int N = S.N, M = S.M;
@@ -1297,7 +1304,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     const int nb = min(nbmax, N - first);
     if (nb <= 0) return;
     RowCtx c;
-    c.S = &S, c.mission = mission;
+    c.S = &S, c.mission = mission, c.lds_avail = lds_doubles - 32;
     c.d = make_dims(N, M, first, nb);
     c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
     double* ctrl = S.ctrl + (size_t)mission * N * 3 * c.d.oq;
@@ -1437,8 +1444,13 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
 
     const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
     bool ok = false;
-    int it_count = 0;
+    int it_count = 0, polished = 0, early_tries = 0;
     double flops = 0, rows_swept = 0;
+    PolishWs pw;
+    pw.cand = (Cand*)w.polish;
+    pw.V = w.polish + 128 * 14;
+    pw.Sg = pw.V + (size_t)129 * d.nj * d.nk;
+    pw.ncand = (int*)(pw.Sg + 128 * 128);
     for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
         it_count = iter;
         // ---- sweep 1: weights, accumulators, residual norms
@@ -1473,6 +1485,19 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             break;
         }
         PROF(2);
+        // EARLY CROSSOVER: the polish returns the exact optimum (KKT-verified on every row) as soon as the interior-point
+        // iterate identifies the active set, which happens several iterations before the 1e-10 termination test: try it
+        // at mu < 1e-6 and once more at mu < 1e-8; a refused attempt leaves the iterate untouched and the loop goes on.
+        if (QP_EARLY_POLISH && S.p.polish && early_tries < 2 && pres < QP_EARLY_TOL && dres < QP_EARLY_TOL && mu < (early_tries == 0 ? QP_EARLY_TOL : 1e-2 * QP_EARLY_TOL)) {
+            early_tries++;
+            const int acc = polish_entry(c, pw, lds, red2, flag2);
+            __syncthreads();
+            PROF(0);
+            if (acc == 0) {
+                ok = true, polished = 1;
+                break;
+            }
+        }
         // ---- Newton matrix and factorisation
         assemble_blocks(c);
         PROF(3);
@@ -1564,13 +1589,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         return;
     }
     // ---- active-set polish
-    int polished = 0;
-    if (S.p.polish) {
-        PolishWs pw;
-        pw.cand = (Cand*)w.polish;
-        pw.V = w.polish + 128 * 14;
-        pw.Sg = pw.V + (size_t)129 * d.nj * d.nk;
-        pw.ncand = (int*)(pw.Sg + 128 * 128);
+    if (S.p.polish && !polished) {
         const int acc = polish_entry(c, pw, lds, red2, flag2);
         polished = acc == 0 ? 1 : 0;
         PROF(0);
@@ -1606,10 +1625,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
 // boundaries (a launch per batch costs the sum over batches of the slowest mission's interior-point iteration count),
 // and with more missions than CUs the hardware dispatcher balances them.
 __global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int passes,
-                                                               int biter, int nbmax) {
+                                                               int biter, int nbmax, int lds_doubles) {
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
-            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0));
+            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0), lds_doubles);
             __threadfence_block();
             __syncthreads();
         }
@@ -1817,7 +1836,7 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (s.p.iteration > 0)
             hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
-                               ws_bytes_per_mission / sizeof(double), s.p.iteration, biter, bs);
+                               ws_bytes_per_mission / sizeof(double), s.p.iteration, biter, bs, (int)(lds / sizeof(double)) - 2);
     }
     const size_t tot2 = (size_t)s.K * N * 3 * M;
     hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
