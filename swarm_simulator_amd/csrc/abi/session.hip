@@ -113,8 +113,23 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     if (bs > N) bs = N;
     s->qp_ws_per_mission = planner_workspace_bytes(N, M, bs);
 
+    // missions that share a map (same host grid pointer and shape, e.g. several passes of a map sweep) share one device copy
+    auto same_grid = [&](int a, int b) {
+        return worlds[a].dist == worlds[b].dist && worlds[a].dim[0] == worlds[b].dim[0] && worlds[a].dim[1] == worlds[b].dim[1] &&
+               worlds[a].dim[2] == worlds[b].dim[2];
+    };
+    std::vector<int> grid_of(K);
+    for (int k = 0; k < K; ++k) {
+        grid_of[k] = k;
+        for (int j = 0; j < k; ++j)
+            if (grid_of[j] == j && same_grid(j, k)) {
+                grid_of[k] = j;
+                break;
+            }
+    }
     size_t grid_bytes = 0;
-    for (int k = 0; k < K; ++k) grid_bytes += al(sizeof(float) * (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2]);
+    for (int k = 0; k < K; ++k)
+        if (grid_of[k] == k) grid_bytes += al(sizeof(float) * (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2]);
     size_t total = grid_bytes + al(sizeof(DevWorld) * K) + al(sizeof(float) * (size_t)K * N * P * 3) + al(sizeof(double) * K * P) +
                    2 * al(sizeof(double) * (size_t)K * N * 9) + al(sizeof(double) * K * N) +
                    2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) +
@@ -146,8 +161,13 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
 #define UP(dst, src, bytes) HIP_TRY(hipMemcpy((void*)(dst), (src), (bytes), hipMemcpyHostToDevice))
     for (int k = 0; k < K; ++k) {
         size_t n = (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2];
-        float* g = A.take<float>(n);
-        UP(g, worlds[k].dist, sizeof(float) * n);
+        float* g;
+        if (grid_of[k] == k) {
+            g = A.take<float>(n);
+            UP(g, worlds[k].dist, sizeof(float) * n);
+        } else {
+            g = const_cast<float*>(s->worlds_h[grid_of[k]].dist);
+        }
         DevWorld& w = s->worlds_h[k];
         for (int a = 0; a < 3; ++a) w.dim[a] = worlds[k].dim[a], w.key_min[a] = worlds[k].key_min[a];
         w.res = worlds[k].res;

@@ -95,6 +95,7 @@ struct QpWs {
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
     int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
+    int* fperm;                     // [nb][M]: (agent, segment) groups ordered by falling row count (sweep work order)
     double* polish;                 // PolishWs storage
     double *rn0, *rn1, *rn2, *rhc;  // per frozen-neighbour row: signed normal and constant  (slack = rhc - rn . x_a)
 };
@@ -104,7 +105,7 @@ __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
                (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
-               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 2) + 1) / 2 + 2 +
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 3) + 1) / 2 + 2 +
                /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8) +
                /* row constants */ 4 * (size_t)nbmax * N * d.oq;
     return n;
@@ -139,7 +140,8 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.flist = (int*)p;
     w.fcnt = w.flist + (size_t)nbmax * d.M * d.N;
     w.fbase = w.fcnt + (size_t)nbmax * d.M;
-    w.polish = p + ((size_t)nbmax * d.M * (d.N + 2) + 1) / 2 + 2;
+    w.fperm = w.fbase + (size_t)nbmax * d.M;
+    w.polish = p + ((size_t)nbmax * d.M * (d.N + 3) + 1) / 2 + 2;
     w.rn0 = w.polish + (128 * 14 + (size_t)129 * dm.nj * dm.nk + 128 * 128 + 8);
     w.rn1 = w.rn0 + (size_t)nbmax * d.N * d.oq;
     w.rn2 = w.rn1 + (size_t)nbmax * d.N * d.oq;
@@ -335,8 +337,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
     constexpr bool pinned_only = (PASS == PASS_PRESOLVE);
     // ---- control points of batch agents: bound + frozen rows
     const int ncp = d.nb * oq;
-    for (int it = threadIdx.x; it < ncp; it += QP_THREADS) {
-        const int a = it / oq, j6 = it % oq, seg = j6 / 6;
+    for (int wi = threadIdx.x; wi < ncp; wi += QP_THREADS) {
+        const int grp = w.fperm[wi / 6], a = grp / d.M, seg = grp % d.M, j6 = 6 * seg + wi % 6, it = a * oq + j6;
         const bool pinned = (j6 < 3 || j6 >= oq - 3);
         if (pinned != pinned_only) continue;
         const int qa = d.first + a;
@@ -407,6 +409,13 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e];
         }
     }
+#ifdef QP_SWEEPSTATS
+    long long sw_t0 = 0;
+    if (PASS == PASS_STEP) {
+        __syncthreads();
+        sw_t0 = wall_clock64();
+    }
+#endif
     // ---- in-batch pairs
     const int npi = d.npb * oq;
     for (int it = threadIdx.x; it < npi; it += QP_THREADS) {
@@ -449,6 +458,12 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             acc[6] = v * n0, acc[7] = v * n1, acc[8] = v * n2;
         }
     }
+#ifdef QP_SWEEPSTATS
+    if (PASS == PASS_STEP) {
+        __syncthreads();
+        if (threadIdx.x == 0) c.S->scalars[(size_t)c.mission * SC_N + 23] += (double)(wall_clock64() - sw_t0);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -544,11 +559,27 @@ __device__ inline double sym3(const double* S, int k, int l) {
     return S[a == 0 ? b : (a == 1 ? 2 + b : 5)];
 }
 
-__device__ void assemble_blocks(const RowCtx& c) {
+__device__ void assemble_blocks(const RowCtx& c, double* lds) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
-    // work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out
+    // stage 1: per (agent, control point) the 3x3 weight sum of ALL its rows (own bounds + frozen neighbours from the
+    // sweep, plus the in-batch pairs it takes part in), parked in LDS when it fits
+    const bool in_lds = nb * oq * 6 <= c.lds_avail;
+    if (in_lds) {
+        for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) {
+            const int e = it % 6, j6 = (it / 6) % oq, a = it / (6 * oq);
+            double sv = w.cpacc[((size_t)a * oq + j6) * 12 + e];
+            for (int o = 0; o < nb; ++o) {
+                if (o == a) continue;
+                const int lo = a < o ? a : o, hi = a < o ? o : a;
+                sv += w.pracc[((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12 + e];
+            }
+            lds[it] = sv;
+        }
+        __syncthreads();
+    }
+    // stage 2: work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out
     const int per_knot = nb * nb * 9;
     for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
         const int j = it / per_knot + 1, r = it % per_knot;
@@ -559,11 +590,15 @@ __device__ void assemble_blocks(const RowCtx& c) {
             const int j6 = 6 * (j - 1) + 3 + p;
             double sv;
             if (a == b) {
-                sv = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
-                for (int o = 0; o < nb; ++o) {
-                    if (o == a) continue;
-                    const int lo = a < o ? a : o, hi = a < o ? o : a;
-                    sv += sym3(w.pracc + ((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12, k, l);
+                if (in_lds) {
+                    sv = sym3(lds + ((size_t)a * oq + j6) * 6, k, l);
+                } else {
+                    sv = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
+                    for (int o = 0; o < nb; ++o) {
+                        if (o == a) continue;
+                        const int lo = a < o ? a : o, hi = a < o ? o : a;
+                        sv += sym3(w.pracc + ((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12, k, l);
+                    }
                 }
             } else {
                 const int lo = a < b ? a : b, hi = a < b ? b : a;
@@ -584,7 +619,7 @@ __device__ void assemble_blocks(const RowCtx& c) {
                 out[(size_t)e * lb + f] = acc;
             }
     }
-    if (d.nj > 1) {
+    if (d.nj > 1 && nk > 36) {  // the wave-register path builds its coupling rows from Ek directly (coupling_row)
         const size_t noff = (size_t)(d.nj - 1) * lb * lb;
         for (size_t it = threadIdx.x; it < noff; it += QP_THREADS) {
             const int j = (int)(it / ((size_t)lb * lb)) + 1;  // couples knot j (cols) and j+1 (rows)
@@ -811,14 +846,18 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
 // Substitutions T du = rhs for the twisted factorisation, factor blocks STAGED THROUGH LDS: waves 2.. prefetch the
 // blocks of step s+1 (coalesced global reads into a double buffer) while waves 0 / 1 run step s of the left / right
 // chain out of LDS with a row (forward) or a column (backward) of each block in VGPRs.  rhs lives in LDS throughout.
-// lds: 2 x 4 blocks of NK*(NK+1) + nj*NK doubles.
+// A stage holds, per chain, the diagonal factor PACKED (lower triangle, column-major: element (r,k), r >= k, at
+// k*NK - k(k-1)/2 + r - k) and the full coupling block (element (r,k) at k*(NK+1) + r): 2 x (2*DG + 2*BLK) + nj*NK
+// doubles = 74 KB for NK = 36, so that two 256-thread workgroups share one CU's LDS.
 template <int NK>
 __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
-    constexpr int LDP = NK + 1, BLK = NK * LDP;
+    constexpr int LDP = NK + 1, BLK = NK * LDP, DG = (NK * (NK + 1) / 2 + 7) & ~7, STG = 2 * DG + 2 * BLK;
+    // stage layout: [0, DG) left diag, [DG, DG+BLK) left coupling, [DG+BLK, 2DG+BLK) right diag, [2DG+BLK, STG) right coupling
+    constexpr int O_LD = 0, O_LO = DG, O_RD = DG + BLK, O_RO = 2 * DG + BLK;
     const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
     const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
-    double* vec = lds + 8 * BLK;    // nj*NK
+    double* vec = lds + 2 * STG;    // nj*NK
     for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
     // block indices handled at step s by the left / right wave (-1: idle)
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
@@ -838,50 +877,68 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         }
         for (int it = t0 + 8 * nt; it < NK * NK; it += nt) dst[(it / NK) * LDP + it % NK] = src[it];
     };
+    auto copy_diag = [&](const double* src, double* dst, int t0, int nt) {  // lower triangle of src[k*NK + r] -> packed
+        for (int base = t0; base < NK * NK; base += 8 * nt) {  // eight loads in flight per lane, then the LDS stores
+            double tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * nt;
+                tmp[u] = it < NK * NK ? src[it] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = base + u * nt, k = it / NK, r = it % NK;
+                if (it < NK * NK && r >= k) dst[k * NK - k * (k - 1) / 2 + r - k] = tmp[u];
+            }
+        }
+    };
     auto stage = [&](int s, double* buf, int t0, int nt) {
         const int jl = left_j(s), jr = right_j(s);
         if (s == SF) {  // middle: L_mid, B_mid, C_mid
-            copy_blk(w.Lf + (size_t)mid * 2 * NK * NK, buf, t0, nt);
-            if (mid > 0) copy_blk(w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK, buf + BLK, t0, nt);
-            if (mid + 1 < nj) copy_blk(w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK, buf + 2 * BLK, t0, nt);
+            copy_diag(w.Lf + (size_t)mid * 2 * NK * NK, buf + O_LD, t0, nt);
+            if (mid > 0) copy_blk(w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK, buf + O_LO, t0, nt);
+            if (mid + 1 < nj) copy_blk(w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK, buf + O_RO, t0, nt);
             return;
         }
         const bool fwd = s < SF;
         if (jl >= 0) {
-            copy_blk(w.Lf + (size_t)jl * 2 * NK * NK, buf, t0, nt);
+            copy_diag(w.Lf + (size_t)jl * 2 * NK * NK, buf + O_LD, t0, nt);
             // forward: B_jl = Lf[jl-1][1] (rows of block jl); backward: B_{jl+1} = Lf[jl][1]
-            if (fwd ? jl > 0 : true) copy_blk(w.Lf + (size_t)(fwd ? jl - 1 : jl) * 2 * NK * NK + NK * NK, buf + BLK, t0, nt);
+            if (fwd ? jl > 0 : true) copy_blk(w.Lf + (size_t)(fwd ? jl - 1 : jl) * 2 * NK * NK + NK * NK, buf + O_LO, t0, nt);
         }
         if (jr >= 0) {
-            copy_blk(w.Lf + (size_t)jr * 2 * NK * NK, buf + 2 * BLK, t0, nt);
+            copy_diag(w.Lf + (size_t)jr * 2 * NK * NK, buf + O_RD, t0, nt);
             // forward: C_jr = Lf[jr+1][1] (rows of block jr); backward: C_{jr-1} = Lf[jr][1]
-            if (fwd ? jr + 1 < nj : true) copy_blk(w.Lf + (size_t)(fwd ? jr + 1 : jr) * 2 * NK * NK + NK * NK, buf + 3 * BLK, t0, nt);
+            if (fwd ? jr + 1 < nj : true) copy_blk(w.Lf + (size_t)(fwd ? jr + 1 : jr) * 2 * NK * NK + NK * NK, buf + O_RO, t0, nt);
         }
     };
     stage(0, lds, tid, QP_THREADS);
     __syncthreads();
     const int wave = tid >> 6, r = tid & 63;
     const int rr = r < NK ? r : 0;
+    // row rr of the packed factor: a[k] = L[rr][k], k <= rr; column rr: a[k] = L[k][rr], k >= rr
+#define DG_ROW(dg, k) ((k) <= rr ? (dg)[(k) * NK - (k) * ((k) - 1) / 2 + rr - (k)] : 0.0)
+#define DG_COL(dg, k) ((k) >= rr ? (dg)[rr * NK - rr * (rr - 1) / 2 + (k) - rr] : 0.0)
     double prev = 0;  // this chain's previous solution vector, element r
     for (int s = 0; s < nsteps; ++s) {
-        double* buf = lds + (s & 1) * 4 * BLK;
+        double* buf = lds + (s & 1) * STG;
         if (wave >= 2) {
-            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * 4 * BLK, tid - 128, QP_THREADS - 128);
+            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * STG, tid - 128, QP_THREADS - 128);
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours, then backward
                 double a[NK], b[NK];
                 double v = vec[mid * NK + rr];
 #pragma unroll
-                for (int k = 0; k < NK; ++k) a[k] = buf[k * LDP + rr];
+                for (int k = 0; k < NK; ++k) a[k] = DG_ROW(buf + O_LD, k);
                 if (mid > 0) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = buf[BLK + k * LDP + rr];
+                    for (int k = 0; k < NK; ++k) b[k] = buf[O_LO + k * LDP + rr];
 #pragma unroll
                     for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid - 1) * NK + k];
                 }
                 if (mid + 1 < nj) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = buf[2 * BLK + k * LDP + rr];
+                    for (int k = 0; k < NK; ++k) b[k] = buf[O_RO + k * LDP + rr];
 #pragma unroll
                     for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid + 1) * NK + k];
                 }
@@ -895,7 +952,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                     v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
                 }
 #pragma unroll
-                for (int k = 0; k < NK; ++k) a[k] = buf[rr * LDP + k];  // column r
+                for (int k = 0; k < NK; ++k) a[k] = DG_COL(buf + O_LD, k);  // column r
 #pragma unroll
                 for (int c = NK - 1; c >= 0; --c) {
                     const double xc = rl(v, c) * rl(inv, c);
@@ -907,25 +964,26 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             const bool fwd = s < SF;
             const int jb = wave == 0 ? left_j(s) : right_j(s);
             if (jb >= 0) {
-                const double* bl = buf + (wave == 0 ? 0 : 2 * BLK);
+                const double* dgp = buf + (wave == 0 ? O_LD : O_RD);
+                const double* bl = buf + (wave == 0 ? O_LO : O_RO);
                 double a[NK], b[NK];
                 double v = vec[jb * NK + rr];
                 const bool first_bwd = !fwd && s == SF + 1;  // neighbour solution comes from the middle block (in LDS)
                 const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
                 if (fwd) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) a[k] = bl[k * LDP + rr];
+                    for (int k = 0; k < NK; ++k) a[k] = DG_ROW(dgp, k);
                     if (has_nb) {
 #pragma unroll
-                        for (int k = 0; k < NK; ++k) b[k] = bl[BLK + k * LDP + rr];
+                        for (int k = 0; k < NK; ++k) b[k] = bl[k * LDP + rr];
 #pragma unroll
                         for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) a[k] = bl[rr * LDP + k];
+                    for (int k = 0; k < NK; ++k) a[k] = DG_COL(dgp, k);
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = bl[BLK + rr * LDP + k];
+                    for (int k = 0; k < NK; ++k) b[k] = bl[rr * LDP + k];
                     if (first_bwd) {
 #pragma unroll
                         for (int k = 0; k < NK; ++k) v -= b[k] * vec[mid * NK + k];
@@ -957,6 +1015,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         }
         __syncthreads();
     }
+#undef DG_ROW
+#undef DG_COL
     for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
     __threadfence_block();
     __syncthreads();
@@ -1406,6 +1466,20 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     __syncthreads();
     const int frozen_free_rows = *flag;
     __syncthreads();
+    // sweep work order: the threads of a wavefront walk the row lists of their control points in lockstep, so a wave
+    // costs as much as its longest list.  Handing out the (agent, segment) groups by falling row count puts lists of
+    // similar length into the same wave (and the long ones into the first round).  Rank sort, one thread per group.
+    for (int it = tid; it < nb * M; it += QP_THREADS) {
+        const int ci = w.fcnt[it];
+        int rank = 0;
+        for (int o = 0; o < nb * M; ++o) {
+            const int co = w.fcnt[o];
+            rank += (co > ci || (co == ci && o < it)) ? 1 : 0;
+        }
+        w.fperm[rank] = it;
+    }
+    __threadfence_block();
+    __syncthreads();
     // tabulate the constants of the surviving rows: n (sign applied) and rhc = n . d_f - (r_a + r_f)
     for (int it = tid; it < nb * M * 6; it += QP_THREADS) {
         const int as = it / 6, i = it % 6, a = as / M, seg = as % M, qa = first + a, j6 = 6 * seg + i;
@@ -1499,7 +1573,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             }
         }
         // ---- Newton matrix and factorisation
-        assemble_blocks(c);
+        assemble_blocks(c, lds);
         PROF(3);
         __threadfence_block();
         __syncthreads();
@@ -1831,7 +1905,7 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 18 * (M - 1) + 32) + 16);
-        lds = std::max(lds, sizeof(double) * ((size_t)8 * nkw * (nkw + 1) + (size_t)(M - 1) * nkw + 64));
+        lds = std::max(lds, sizeof(double) * ((size_t)4 * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (s.p.iteration > 0)
