@@ -39,7 +39,9 @@
 #define QP_EARLY_POLISH 1  // try the active-set polish before the interior-point loop has fully converged
 #endif
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
-#define POLISH_LDS_DOUBLES (96 * 97 / 2 + 128 + 128 + 96 + 96 + 96 + (96 + 128 + 128 + 8) / 2 + 8)
+#define PL_NC 256    // polish: candidate rows
+#define PL_PMAX 160  // polish: rows simultaneously active in the dual solve
+#define POLISH_LDS_DOUBLES (PL_PMAX * (PL_PMAX + 1) / 2 + 2 * PL_NC + 3 * PL_PMAX + (PL_PMAX + 2 * PL_NC + 8) / 2 + 8)
 
 namespace {
 
@@ -109,7 +111,7 @@ __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
                (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 3) + 1) / 2 + 2 +
-               /* polish: cand, V, S, counters */ (128 * 14 + (size_t)129 * d.nj * d.nk + 128 * 128 + 8) +
+               /* polish: cand, V, S, counters */ (PL_NC * 14 + (size_t)(PL_NC + 1) * d.nj * d.nk + PL_NC * PL_NC + 8) +
                /* row constants */ 4 * (size_t)nbmax * N * d.oq;
     return n;
 }
@@ -145,7 +147,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.fbase = w.fcnt + (size_t)nbmax * d.M;
     w.fperm = w.fbase + (size_t)nbmax * d.M;
     w.polish = p + ((size_t)nbmax * d.M * (d.N + 3) + 1) / 2 + 2;
-    w.rn0 = w.polish + (128 * 14 + (size_t)129 * dm.nj * dm.nk + 128 * 128 + 8);
+    w.rn0 = w.polish + (PL_NC * 14 + (size_t)(PL_NC + 1) * dm.nj * dm.nk + PL_NC * PL_NC + 8);
     w.rn1 = w.rn0 + (size_t)nbmax * d.N * d.oq;
     w.rn2 = w.rn1 + (size_t)nbmax * d.N * d.oq;
     w.rhc = w.rn2 + (size_t)nbmax * d.N * d.oq;
@@ -1525,9 +1527,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     double flops = 0, rows_swept = 0;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
-    pw.V = w.polish + 128 * 14;
-    pw.Sg = pw.V + (size_t)129 * d.nj * d.nk;
-    pw.ncand = (int*)(pw.Sg + 128 * 128);
+    pw.V = w.polish + PL_NC * 14;
+    pw.Sg = pw.V + (size_t)(PL_NC + 1) * d.nj * d.nk;
+    pw.ncand = (int*)(pw.Sg + PL_NC * PL_NC);
     for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
         it_count = iter;
         // ---- sweep 1: weights, accumulators, residual norms
