@@ -95,9 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--agents", type=int, default=64, help="mission_<N>agents_15.json (64 = headline, 16 = C2)")
-    ap.add_argument("--missions-per-gpu", type=int, default=250,
-                    help="missions in flight per step on each GPU: 250 = five passes of the reference's 50-map sweep, "
-                         "one workgroup per CU (256 CUs); 50 = exactly one sweep")
+    ap.add_argument("--missions-per-gpu", type=int, default=1000,
+                    help="missions resident per step on each GPU: 1000 = twenty passes of the reference's 50-map sweep (one "
+                         "workgroup per mission, ~4 per CU, handed out by the dispatcher as CUs free up); 50 = exactly one sweep")
     ap.add_argument("--batch-size", type=int, default=4, help="plan/batch_size (4 = plan_rbp_test.launch; 8 = BASELINE config C5)")
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
@@ -164,9 +164,10 @@ def main():
 
     if rank == 0:
         value = n_total / secs
-        # dominant kernel: the batch QP kernel.  Algorithmic work per launch = flops of the dense block
-        # factorisations/solves it logs (F = sum_factor 7/3 nk^3 per knot + sum_solve 4 nk^2 per knot);
-        # a step launches (iterations x batches) QP kernels; achieved = flops per step / planner time per step.
+        # dominant kernel: the batch QP kernel, ONE launch per step (every workgroup runs its mission's whole batch
+        # schedule).  Algorithmic work per launch = flops of the dense block factorisations/solves it logs (SURVEY.md 8d:
+        # F = sum_factor 7/3 nk^3 per knot + sum_solve 4 nk^2 per knot); achieved = flops per launch / planner-stage time
+        # (HIP events on the launch stream; the stage is the QP launch plus three sub-millisecond helper kernels).
         qp_tflops = ct["qp_flops"] / (planner_ms * 1e-3) / 1e12
         # HBM-side bytes per qp_batch_kernel launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc.json
