@@ -267,10 +267,20 @@ struct RowCtx {
     const double* radius;  // [N]
 };
 
+// 1/x for the row arithmetic of the sweeps: v_rcp_f64 plus two Newton steps (relative error ~1e-16 for normal x > 0).
+// An IEEE division costs three times as many instructions (div_scale, div_fmas, div_fixup); the sweeps are issue-bound.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 template <int PASS>
 __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, size_t r, const QpWs& w, PassIO& io,
                                        double& wgt, double& v) {
-    // slack = h - g.x ; returns weight wgt and rhs scalar v where relevant
+    // slack = h - g.x ; returns weight wgt and rhs scalar v where relevant.  Step-length limits are tracked as
+    // io.vmax = max(-ds/s, -dz/z) (the caller takes the reciprocal), which needs no data-dependent division.
     if (PASS == PASS_INIT) {
         double s = slack < io.s_floor ? io.s_floor : slack;
         w.s[r] = s;
@@ -278,36 +288,36 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
     } else if (PASS == PASS_BUILD) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
-        wgt = 1.0 / (s / z + io.dreg);
+        wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
         v = -wgt * (rg - s);  // predictor: rc / z = s
         io.sum0 += s * z;
         io.vmax = fmax(io.vmax, fabs(rg));
     } else if (PASS == PASS_AFF) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
-        wgt = 1.0 / (s / z + io.dreg);
+        const double iz = fast_rcp(z), is = fast_rcp(s);
+        wgt = z * fast_rcp(s + io.dreg * z);
         const double dza = wgt * (gdx_a + rg - s);
-        const double dsa = (-s * z - s * dza) / z;
+        const double dsa = -s - s * dza * iz;  // (-s z - s dza) / z
         w.cc[r] = dsa * dza;
-        if (dsa < 0) io.vmin = fmin(io.vmin, -s / dsa);
-        if (dza < 0) io.vmin = fmin(io.vmin, -z / dza);
+        io.vmax = fmax(io.vmax, fmax(-dsa * is, -dza * iz));
         io.sum0 += s * z, io.sum1 += s * dza + z * dsa, io.sum2 += dsa * dza;
     } else if (PASS == PASS_CORR_RHS) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
-        wgt = 1.0 / (s / z + io.dreg);
+        wgt = z * fast_rcp(s + io.dreg * z);
         const double rcc = s * z + w.cc[r] - io.sigma_mu;
-        v = -wgt * (rg - rcc / z);
+        v = -wgt * (rg - rcc * fast_rcp(z));
     } else if (PASS == PASS_STEP) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
-        wgt = 1.0 / (s / z + io.dreg);
+        const double iz = fast_rcp(z), is = fast_rcp(s);
+        wgt = z * fast_rcp(s + io.dreg * z);
         const double rcc = s * z + w.cc[r] - io.sigma_mu;
-        const double dz = wgt * (gdx + rg - rcc / z);
-        const double ds = (-rcc - s * dz) / z;
+        const double dz = wgt * (gdx + rg - rcc * iz);
+        const double ds = -(rcc + s * dz) * iz;
         w.ds[r] = ds, w.dz[r] = dz;
-        if (ds < 0) io.vmin = fmin(io.vmin, -s / ds);
-        if (dz < 0) io.vmin = fmin(io.vmin, -z / dz);
+        io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
     } else if (PASS == PASS_NBHD) {
         const double p = (w.s[r] + io.alpha * w.ds[r]) * (w.z[r] + io.alpha * w.dz[r]);
         io.sum0 += p;
@@ -1605,11 +1615,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         apply_F(d, w, w.rhs, w.dxa);
         __threadfence_block();
         __syncthreads();
-        io.sum0 = io.sum1 = io.sum2 = 0, io.vmin = 1.0;
+        io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 1.0;  // vmax = max(1, max -d/x): a_aff = min(1, min -x/d)
         PROF(5);
         row_pass<PASS_AFF>(c, io);
         PROF(7);
-        const double a_aff = block_reduce(io.vmin, 2, red);
+        const double a_aff = 1.0 / block_reduce(io.vmax, 1, red);
         const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
         const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows_free;
         double sigma = mu_aff / mu;
@@ -1638,11 +1648,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __threadfence_block();
         __syncthreads();
         flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
-        io.vmin = 1e300;
+        io.vmax = 0.99;  // alpha = min(1, 0.99 * min -x/d) = 0.99 / max(0.99, max -d/x)
         PROF(5);
         row_pass<PASS_STEP>(c, io);
         PROF(9);
-        double alpha = fmin(1.0, 0.99 * block_reduce(io.vmin, 2, red));
+        double alpha = 0.99 / block_reduce(io.vmax, 1, red);
         __threadfence_block();
         __syncthreads();
         // ---- wide neighbourhood: no product below 1e-3 * mu(alpha)
