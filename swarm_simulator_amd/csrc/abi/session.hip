@@ -46,6 +46,7 @@ struct Arena {
 
 struct rbp_session {
     int device = 0;
+    int n_cu = 256;
     DevSession d{};
     rbp_param param{};
     Arena arena;
@@ -111,7 +112,11 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     int bs = param->sequential ? param->batch_size : N;
     if (bs <= 0) bs = 1;
     if (bs > N) bs = N;
-    s->qp_ws_per_mission = planner_workspace_bytes(N, M, bs);
+    s->qp_ws_per_mission = std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs));
+    {
+        hipDeviceProp_t prop;
+        s->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
 
     // missions that share a map (same host grid pointer and shape, e.g. several passes of a map sweep) share one device copy
     auto same_grid = [&](int a, int b) {
@@ -275,7 +280,15 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
     if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
-    if (stages & RBP_STAGE_PLANNER) launch_planner(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+    if (stages & RBP_STAGE_PLANNER) {
+        // two workgroups per CU (the 128-VGPR build) pay off once every CU has at least two missions to overlap
+        const char* force = getenv("RBP_QP_VARIANT");  // developer override: "w2" | "w4"
+        const bool w4 = force ? (force[0] == 'w' && force[1] == '4') : s->d.K >= 2 * s->n_cu;
+        if (w4)
+            launch_planner_w4(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+        else
+            launch_planner_w2(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+    }
     HIP_TRY(hipGetLastError());
     return RBP_OK;
 }

@@ -29,6 +29,12 @@
 #endif
 #define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
 #define QP_MAX_ITERS 80
+#ifndef QP_WAVES_PER_EU
+#define QP_WAVES_PER_EU (512 / QP_THREADS)  // 2 with 512 threads: all 256 VGPRs for the wave-register path
+#endif
+#ifndef QP_RCP_NEWTON
+#define QP_RCP_NEWTON 2
+#endif
 #ifndef QP_EARLY_TRIES
 #define QP_EARLY_TRIES 1
 #endif
@@ -40,8 +46,13 @@
 #endif
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
 #define PL_NC 256    // polish: candidate rows
-#define PL_PMAX 160  // polish: rows simultaneously active in the dual solve
-#define POLISH_LDS_DOUBLES (PL_PMAX * (PL_PMAX + 1) / 2 + 2 * PL_NC + 3 * PL_PMAX + (PL_PMAX + 2 * PL_NC + 8) / 2 + 8)
+#define PL_PMAX 160  // polish: rows simultaneously active in the dual solve (wide batches; 112 on the wave path, whose
+                     // workgroups are meant to share a CU's LDS in pairs)
+__host__ __device__ inline int polish_pmax(int nk) { return nk <= 36 ? 112 : PL_PMAX; }
+__host__ __device__ inline int polish_lds_doubles(int nk) {
+    const int pm = polish_pmax(nk);
+    return pm * (pm + 1) / 2 + 2 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
+}
 
 namespace {
 
@@ -272,7 +283,9 @@ struct RowCtx {
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
+#if QP_RCP_NEWTON > 1
     r = fma(fma(-x, r, 1.0), r, r);
+#endif
     return r;
 }
 
@@ -479,6 +492,20 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         if (threadIdx.x == 0) c.S->scalars[(size_t)c.mission * SC_N + 23] += (double)(wall_clock64() - sw_t0);
     }
 #endif
+}
+
+// A sweep of the interior-point loop.  With 256 VGPRs per wave it is a stand-alone function (own register allocation,
+// by-value context: see BlkArgs below; +2 %); in the 128-VGPR build the by-value context would travel through scratch
+// memory and inlining is the better choice (measured).
+#if QP_WAVES_PER_EU >= 4
+#define SWEEP_INLINE __forceinline__
+#else
+#define SWEEP_INLINE __noinline__
+#endif
+template <int PASS>
+__device__ SWEEP_INLINE PassIO sweep(RowCtx c, PassIO io) {
+    row_pass<PASS>(c, io);
+    return io;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -767,6 +794,146 @@ __device__ __forceinline__ bool chol_rows(double (&a)[NK]) {  // right-looking; 
     return ok;
 }
 
+#if QP_WAVES_PER_EU >= 4
+// ---- low-register variant (<= 128 VGPRs, so that two 512-thread workgroups share a CU): one block row per lane in
+// VGPRs at a time.  The factor L_jj is parked in LDS (row-major, in the scratch the rank-k update just vacated) and the
+// coupling solve x L_jj' = t reads L[c][k] as LDS broadcasts in dot-product form; t (a row of T_{j+1,j}, three non-zeros
+// out of Ek) is generated on the fly, so neither the coupling row nor the factor row is live next to x.
+#define WF_LDL (36 + 1)
+
+template <int NK>
+__device__ __forceinline__ void syrk_rows_lo(double (&a)[NK], double* ldsW, int lane, int rr) {
+    // a -= (B B')[rr][:] with B in ldsW[0 .. 48*SYRK_LDB); three MFMA tiles at a time (24 accumulator VGPRs)
+    const double* ldsB = ldsW;
+    double* ldsU = ldsW + 48 * SYRK_LDB;
+    constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        d4 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = d4{0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) {
+            const double opi = ldsB[(16 * ti + li) * SYRK_LDB + 4 * ks + lk];
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const double opj = ldsB[(16 * tj + li) * SYRK_LDB + 4 * ks + lk];
+                acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opi, opj, acc[tj], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ldsU[(16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li] = acc[tj][g];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// factor row a (lane rr) -> global Lf block [k][r] and LDS row-major copy + reciprocal diagonal
+template <int NK>
+__device__ __forceinline__ void park_factor(const double (&a)[NK], double* L0, double* ldsL, double* ldsInv, int r, bool act) {
+    if (act) {
+        double dg = 1.0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            L0[k * NK + r] = k <= r ? a[k] : 0.0;
+            ldsL[r * WF_LDL + k] = a[k];
+            dg = (r == k) ? a[k] : dg;
+        }
+        ldsInv[r] = 1.0 / dg;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// x <- t L^{-T} for the coupling row t of lane rr towards the next block of the chain (coupling_row)
+template <int NK>
+__device__ __forceinline__ void coupling_solve_lo(const QpWs& w, int j, int dir, int rr, const double* ldsL, const double* ldsInv,
+                                                  double (&x)[NK]) {
+    const double* E = w.Ek + 9 * (dir > 0 ? j + 1 : j);
+    const double e0 = dir > 0 ? E[rr % 3] : E[3 * (rr % 3)], e1 = dir > 0 ? E[3 + rr % 3] : E[3 * (rr % 3) + 1],
+                 e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
+    const int c0 = 3 * (rr / 3);  // the row's three non-zeros sit in columns c0 .. c0+2
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+        double s0 = (c == c0) ? e0 : ((c == c0 + 1) ? e1 : ((c == c0 + 2) ? e2 : 0.0)), s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < c; ++k) {
+            if (k & 1)
+                s1 -= x[k] * ldsL[c * WF_LDL + k];
+            else
+                s0 -= x[k] * ldsL[c * WF_LDL + k];
+        }
+        x[c] = (s0 + s1) * ldsInv[c];
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW) {
+    const int r = threadIdx.x & 63;
+    const bool act = r < NK;
+    const int rr = act ? r : 0;
+    double* ldsB = ldsW;
+    double* ldsL = ldsW + 48 * SYRK_LDB;  // overlays the U tiles of the rank-k update
+    double* ldsInv = ldsL + 40 * WF_LDL;
+    bool ok = true;
+    for (int i = 0, j = j0; i < count; ++i, j += dir) {
+        double a[NK];
+        const double* Tg = w.Td + (size_t)j * NK * NK;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
+        if (i > 0) syrk_rows_lo<NK>(a, ldsW, r, rr);
+        if (!chol_rows<NK>(a)) ok = false;
+        double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
+        park_factor<NK>(a, L0, ldsL, ldsInv, r, act);
+        {
+            double x[NK];
+            coupling_solve_lo<NK>(w, j, dir, rr, ldsL, ldsInv, x);
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = x[k], ldsB[r * SYRK_LDB + k] = x[k];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return ok;
+}
+
+template <int NK>
+__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW) {
+    const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
+    const bool act = r < NK;
+    const int rr = act ? r : 0;
+    double a[NK];
+    const double* Tg = w.Td + (size_t)mid * NK * NK;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+    for (int side = 0; side < 2; ++side) {
+        const int jn = side == 0 ? mid - 1 : mid + 1;
+        if (jn < 0 || jn >= d.nj) continue;
+        const double* Bm = w.Lf + (size_t)jn * 2 * NK * NK + NK * NK;
+        if (act) {
+            for (int k = 0; k < NK; ++k) ldsW[r * SYRK_LDB + k] = Bm[k * NK + r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        syrk_rows_lo<NK>(a, ldsW, r, rr);
+    }
+    if (!chol_rows<NK>(a)) return false;
+    double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
+    }
+    return true;
+}
+#else
 // one chain: blocks j0, j0+dir, ... (count of them)
 template <int NK>
 __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW) {
@@ -833,6 +1000,8 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     }
     return true;
 }
+
+#endif
 
 // whole twisted factorisation; every thread of the workgroup calls it.  flag: LDS int.
 template <int NK>
@@ -941,21 +1110,17 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * STG, tid - 128, QP_THREADS - 128);
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours, then backward
-                double a[NK], b[NK];
+                double a[NK];
                 double v = vec[mid * NK + rr];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) a[k] = DG_ROW(buf + O_LD, k);
                 if (mid > 0) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = buf[O_LO + k * LDP + rr];
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid - 1) * NK + k];
+                    for (int k = 0; k < NK; ++k) v -= buf[O_LO + k * LDP + rr] * vec[(mid - 1) * NK + k];
                 }
                 if (mid + 1 < nj) {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = buf[O_RO + k * LDP + rr];
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= b[k] * vec[(mid + 1) * NK + k];
+                    for (int k = 0; k < NK; ++k) v -= buf[O_RO + k * LDP + rr] * vec[(mid + 1) * NK + k];
                 }
                 double dg = 1.0;
 #pragma unroll
@@ -981,30 +1146,26 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (jb >= 0) {
                 const double* dgp = buf + (wave == 0 ? O_LD : O_RD);
                 const double* bl = buf + (wave == 0 ? O_LO : O_RO);
-                double a[NK], b[NK];
+                double a[NK];
                 double v = vec[jb * NK + rr];
                 const bool first_bwd = !fwd && s == SF + 1;  // neighbour solution comes from the middle block (in LDS)
                 const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
                 if (fwd) {
 #pragma unroll
                     for (int k = 0; k < NK; ++k) a[k] = DG_ROW(dgp, k);
-                    if (has_nb) {
+                    if (has_nb) {  // coupling block read straight from LDS: only the diagonal row is held in VGPRs
 #pragma unroll
-                        for (int k = 0; k < NK; ++k) b[k] = bl[k * LDP + rr];
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                        for (int k = 0; k < NK; ++k) v -= bl[k * LDP + rr] * rl(prev, k);
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < NK; ++k) a[k] = DG_COL(dgp, k);
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) b[k] = bl[rr * LDP + k];
                     if (first_bwd) {
 #pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= b[k] * vec[mid * NK + k];
+                        for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * vec[mid * NK + k];
                     } else {
 #pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= b[k] * rl(prev, k);
+                        for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * rl(prev, k);
                     }
                 }
                 double dg = 1.0;
@@ -1545,7 +1706,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- sweep 1: weights, accumulators, residual norms
         io.sum0 = 0, io.vmax = 0;
         PROF(0);
-        row_pass<PASS_BUILD>(c, io);
+        io = sweep<PASS_BUILD>(c, io);
         PROF(1);
         const double gap = block_reduce(io.sum0, 0, red);
         const double pres = block_reduce(io.vmax, 1, red);
@@ -1617,7 +1778,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __syncthreads();
         io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 1.0;  // vmax = max(1, max -d/x): a_aff = min(1, min -x/d)
         PROF(5);
-        row_pass<PASS_AFF>(c, io);
+        io = sweep<PASS_AFF>(c, io);
         PROF(7);
         const double a_aff = 1.0 / block_reduce(io.vmax, 1, red);
         const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
@@ -1628,7 +1789,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- corrector
         __threadfence_block();
         __syncthreads();
-        row_pass<PASS_CORR_RHS>(c, io);
+        io = sweep<PASS_CORR_RHS>(c, io);
         PROF(8);
         __threadfence_block();
         __syncthreads();
@@ -1650,7 +1811,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
         io.vmax = 0.99;  // alpha = min(1, 0.99 * min -x/d) = 0.99 / max(0.99, max -d/x)
         PROF(5);
-        row_pass<PASS_STEP>(c, io);
+        io = sweep<PASS_STEP>(c, io);
         PROF(9);
         double alpha = 0.99 / block_reduce(io.vmax, 1, red);
         __threadfence_block();
@@ -1658,7 +1819,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- wide neighbourhood: no product below 1e-3 * mu(alpha)
         for (int bt = 0; bt < 40; ++bt) {
             io.alpha = alpha, io.sum0 = 0, io.vmin = 1e300;
-            row_pass<PASS_NBHD>(c, io);
+            io = sweep<PASS_NBHD>(c, io);
             const double mu_new = block_reduce(io.sum0, 0, red) / nrows_free;
             const double pmin = block_reduce(io.vmin, 2, red);
             rows_swept += nrows_free;
@@ -1667,7 +1828,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         }
         PROF(10);
         io.alpha = alpha;
-        row_pass<PASS_UPDATE>(c, io);
+        io = sweep<PASS_UPDATE>(c, io);
         for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
             const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
             ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
@@ -1717,7 +1878,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
 // over `biter` batches) in one launch: missions are independent, so nothing forces them to wait for each other at batch
 // boundaries (a launch per batch costs the sum over batches of the slowest mission's interior-point iteration count),
 // and with more missions than CUs the hardware dispatcher balances them.
-__global__ __launch_bounds__(QP_THREADS, 512 / QP_THREADS) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int passes,
+__global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int passes,
                                                                int biter, int nbmax, int lds_doubles) {
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
@@ -1893,11 +2054,19 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
 
 }  // namespace
 
-size_t planner_workspace_bytes(int N, int M, int batch_size_eff) {
+// This file is compiled twice (csrc/Makefile): QP_WAVES_PER_EU=2 (all 256 VGPRs, one workgroup per CU: fastest single
+// mission) and QP_WAVES_PER_EU=4 (128 VGPRs, low-register factor chain, two workgroups per CU: +6 % throughput when there
+// are at least two missions per CU).  QP_SUFFIX names the entry points; abi/session.hip picks one per launch.
+#ifndef QP_SUFFIX
+#define QP_SUFFIX _w2
+#endif
+#define QP_CAT2(a, b) a##b
+#define QP_CAT(a, b) QP_CAT2(a, b)
+size_t QP_CAT(planner_workspace_bytes, QP_SUFFIX)(int N, int M, int batch_size_eff) {
     return (ws_doubles(N, M, batch_size_eff) * sizeof(double) + 255) & ~size_t(255);
 }
 
-void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st) {
+void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st) {
     const int N = s.N, M = s.M;
     // setBatch (rbp_planner.hpp:849-872)
     int bs = s.p.sequential ? s.p.batch_size : N;
@@ -1923,7 +2092,7 @@ void launch_planner(const DevSession& s, void* qp_ws, size_t ws_bytes_per_missio
         // wave path's staged substitutions (a short last batch may take the wave path even when bs > 4)
         const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
-        lds = std::max(lds, sizeof(double) * (size_t)(POLISH_LDS_DOUBLES + 18 * (M - 1) + 32) + 16);
+        lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
         lds = std::max(lds, sizeof(double) * ((size_t)4 * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

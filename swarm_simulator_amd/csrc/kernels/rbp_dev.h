@@ -61,5 +61,8 @@ enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
 // launchers (defined in the .hip files)
 void launch_corridor(const DevSession& s, hipStream_t st);
-void launch_planner(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
-size_t planner_workspace_bytes(int N, int M, int batch_size_eff);
+// kernels/qp.hip is built twice: _w2 = 256 VGPRs, one workgroup per CU; _w4 = 128 VGPRs, two workgroups per CU
+void launch_planner_w2(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
+void launch_planner_w4(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
+size_t planner_workspace_bytes_w2(int N, int M, int batch_size_eff);
+size_t planner_workspace_bytes_w4(int N, int M, int batch_size_eff);
