@@ -9,6 +9,13 @@ import bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_shards_are_disjoint_and_cover_the_sweep():
     for ws in (1, 2, 4, 8):
         per = 50 // ws
@@ -35,7 +42,7 @@ def test_two_rank_gloo_aggregate(tmp_path):
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
@@ -96,7 +103,7 @@ def test_two_rank_gloo_sharded_corridor(tmp_path):
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
