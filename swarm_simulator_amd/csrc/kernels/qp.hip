@@ -802,8 +802,9 @@ __device__ __forceinline__ bool chol_rows(double (&a)[NK]) {  // right-looking; 
 #define WF_LDL (36 + 1)
 
 template <int NK>
-__device__ __forceinline__ void syrk_rows_lo(double (&a)[NK], double* ldsW, int lane, int rr) {
-    // a -= (B B')[rr][:] with B in ldsW[0 .. 48*SYRK_LDB); three MFMA tiles at a time (24 accumulator VGPRs)
+__device__ __forceinline__ void syrk_tiles_lo(double* ldsW, int lane, bool accumulate) {
+    // U (+)= B B' (lower 16x16 tiles) with B in ldsW[0 .. 48*SYRK_LDB), U in the scratch behind it; three MFMA tiles at a
+    // time (24 accumulator VGPRs), and no block row is live here: the caller loads it afterwards and subtracts its U row
     const double* ldsB = ldsW;
     double* ldsU = ldsW + 48 * SYRK_LDB;
     constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
@@ -824,12 +825,11 @@ __device__ __forceinline__ void syrk_rows_lo(double (&a)[NK], double* ldsW, int 
 #pragma unroll
         for (int tj = 0; tj <= ti; ++tj)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ldsU[(16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li] = acc[tj][g];
+            for (int g = 0; g < 4; ++g) {
+                double* u = ldsU + (16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li;
+                *u = accumulate ? *u + acc[tj][g] : acc[tj][g];
+            }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -883,11 +883,18 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
     double* ldsInv = ldsL + 40 * WF_LDL;
     bool ok = true;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
+        if (i > 0) syrk_tiles_lo<NK>(ldsW, r, false);
         double a[NK];
         const double* Tg = w.Td + (size_t)j * NK * NK;
+        const double* ldsU = ldsW + 48 * SYRK_LDB;
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
-        if (i > 0) syrk_rows_lo<NK>(a, ldsW, r, rr);
+        if (i > 0) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         if (!chol_rows<NK>(a)) ok = false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         park_factor<NK>(a, L0, ldsL, ldsInv, r, act);
@@ -910,10 +917,7 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
     const bool act = r < NK;
     const int rr = act ? r : 0;
-    double a[NK];
-    const double* Tg = w.Td + (size_t)mid * NK * NK;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+    int nsy = 0;
     for (int side = 0; side < 2; ++side) {
         const int jn = side == 0 ? mid - 1 : mid + 1;
         if (jn < 0 || jn >= d.nj) continue;
@@ -923,7 +927,17 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        syrk_rows_lo<NK>(a, ldsW, r, rr);
+        syrk_tiles_lo<NK>(ldsW, r, nsy > 0);
+        nsy++;
+    }
+    double a[NK];
+    const double* Tg = w.Td + (size_t)mid * NK * NK;
+    const double* ldsU = ldsW + 48 * SYRK_LDB;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+    if (nsy > 0) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];
     }
     if (!chol_rows<NK>(a)) return false;
     double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
