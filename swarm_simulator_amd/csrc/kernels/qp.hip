@@ -494,19 +494,19 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
 #endif
 }
 
-// A sweep of the interior-point loop.  With 256 VGPRs per wave it is a stand-alone function (own register allocation,
-// by-value context: see BlkArgs below; +2 %); in the 128-VGPR build the by-value context would travel through scratch
-// memory and inlining is the better choice (measured).
-#if QP_WAVES_PER_EU >= 4
-#define SWEEP_INLINE __forceinline__
-#else
-#define SWEEP_INLINE __noinline__
-#endif
+// A sweep of the interior-point loop.  In the 256-VGPR build it is a stand-alone function (own register allocation,
+// +3 %) that reads the row context from an LDS copy made once per batch QP (passing the 500-byte struct by value would
+// travel through scratch memory); in the 128-VGPR build inlining measured 1.4 % better.
 template <int PASS>
-__device__ SWEEP_INLINE PassIO sweep(RowCtx c, PassIO io) {
-    row_pass<PASS>(c, io);
+__device__ __noinline__ PassIO sweep(const RowCtx* cl, PassIO io) {
+    row_pass<PASS>(*cl, io);
     return io;
 }
+#if QP_WAVES_PER_EU >= 4
+#define SWEEP(PASS) row_pass<PASS>(c, io)
+#else
+#define SWEEP(PASS) io = sweep<PASS>(&c_lds, io)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // control-space <-> reduced-space maps
@@ -1693,6 +1693,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     __syncthreads();
     PROF_DECL;
     PassIO io;
+    __shared__ RowCtx c_lds;  // the sweeps' view of the row context (see sweep<>)
+    __syncthreads();
+    if (tid == 0) c_lds = c;
+    __syncthreads();
     io.mu0 = 1e-1, io.s_floor = 1e-1, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
     // presolve: constant rows (pinned control points) must hold within 1e-6 (CPLEX default feasibility tolerance)
     io.vmax = 0;
@@ -1720,7 +1724,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- sweep 1: weights, accumulators, residual norms
         io.sum0 = 0, io.vmax = 0;
         PROF(0);
-        io = sweep<PASS_BUILD>(c, io);
+        SWEEP(PASS_BUILD);
         PROF(1);
         const double gap = block_reduce(io.sum0, 0, red);
         const double pres = block_reduce(io.vmax, 1, red);
@@ -1792,7 +1796,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __syncthreads();
         io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 1.0;  // vmax = max(1, max -d/x): a_aff = min(1, min -x/d)
         PROF(5);
-        io = sweep<PASS_AFF>(c, io);
+        SWEEP(PASS_AFF);
         PROF(7);
         const double a_aff = 1.0 / block_reduce(io.vmax, 1, red);
         const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
@@ -1803,7 +1807,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- corrector
         __threadfence_block();
         __syncthreads();
-        io = sweep<PASS_CORR_RHS>(c, io);
+        SWEEP(PASS_CORR_RHS);
         PROF(8);
         __threadfence_block();
         __syncthreads();
@@ -1825,7 +1829,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
         io.vmax = 0.99;  // alpha = min(1, 0.99 * min -x/d) = 0.99 / max(0.99, max -d/x)
         PROF(5);
-        io = sweep<PASS_STEP>(c, io);
+        SWEEP(PASS_STEP);
         PROF(9);
         double alpha = 0.99 / block_reduce(io.vmax, 1, red);
         __threadfence_block();
@@ -1833,7 +1837,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- wide neighbourhood: no product below 1e-3 * mu(alpha)
         for (int bt = 0; bt < 40; ++bt) {
             io.alpha = alpha, io.sum0 = 0, io.vmin = 1e300;
-            io = sweep<PASS_NBHD>(c, io);
+            SWEEP(PASS_NBHD);
             const double mu_new = block_reduce(io.sum0, 0, red) / nrows_free;
             const double pmin = block_reduce(io.vmin, 2, red);
             rows_swept += nrows_free;
@@ -1842,7 +1846,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         }
         PROF(10);
         io.alpha = alpha;
-        io = sweep<PASS_UPDATE>(c, io);
+        SWEEP(PASS_UPDATE);
         for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
             const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
             ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
