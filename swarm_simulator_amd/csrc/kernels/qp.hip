@@ -51,7 +51,7 @@
 __host__ __device__ inline int polish_pmax(int nk) { return nk <= 36 ? 112 : PL_PMAX; }
 __host__ __device__ inline int polish_lds_doubles(int nk) {
     const int pm = polish_pmax(nk);
-    return pm * (pm + 1) / 2 + 2 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
+    return pm * (pm + 1) / 2 + 3 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
 }
 
 namespace {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
     } else if (PASS == PASS_CAND) {
         const double s = w.s[r], z = w.z[r];
-        wgt = (z > s || s < 1e-6) ? 1.0 : 0.0;  // candidate for the active set
+        wgt = (z > s || s < 1e-6) ? fmax(z / s, 1e-300) : 0.0;  // candidate for the active set; the value orders the warm start
         w.cc[r] = wgt;
         v = slack;
     } else if (PASS == PASS_VERIFY) {
@@ -391,7 +391,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, wgt, v);
                 if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0)
                     emit_cand(d, w, *c.pw, r, j6, a, -1, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack,
-                              (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo);
+                              (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo, wgt);
                 if (accum) {
                     const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);  // diagonal slots of the packed 3x3
                     if (PASS == PASS_BUILD) {
@@ -414,7 +414,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             const double slack = w.rhc[fr] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
             double wgt = 0, v = 0;
             row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
-            if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0);
+            if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
             if (accum) {
                 if (PASS == PASS_BUILD) {
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
@@ -474,7 +474,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         }
         double wgt = 0, v = 0;
         row_op<PASS>(slack, ga, gd, r, w, io, wgt, v);
-        if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0);
+        if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
         if (accum) {
             double* acc = w.pracc + (size_t)it * 12;
             if (PASS == PASS_BUILD) {
