@@ -208,3 +208,24 @@ def test_error_codes_match_the_reference_failure_sites():
     pr4.sfc_box[0, 0, 3] = pr4.sfc_box[0, 0, 0] + 0.05
     pl4 = planner.RBPPlanner(c4.mission, c4.param)
     assert pl4.update(False, pr4) is False and pl4.rc == A.RBP_ERR_QP_FAILED
+
+
+def test_sweep_driver_serial_and_batched(capsys):
+    """swarm_simulator_amd.test_all — the reference's map-sweep main loop (swarm_traj_planner_rbp_test_all.cpp:49-103) on
+    three maps, once with the synchronous calls and once with all maps in one device session: same costs."""
+    from swarm_simulator_amd import test_all
+    assert test_all.main(["--mission", "mission_16agents_15.json", "--maps", "2-4", "--mode", "serial"]) == 0
+    serial = [l for l in capsys.readouterr().out.splitlines() if l.startswith("map") and "QP total cost" in l]
+    assert test_all.main(["--mission", "mission_16agents_15.json", "--maps", "2-4", "--mode", "batched"]) == 0
+    batched = [l for l in capsys.readouterr().out.splitlines() if l.startswith("map") and "QP total cost" in l]
+    assert len(serial) == len(batched) == 3
+    cost = lambda l: float(l.split("QP total cost")[1].split()[0])
+    ratio = lambda l: float(l.split("safety margin ratio")[1].split()[0])
+    span = lambda l: float(l.split("makespan")[1].split()[0])
+    same = 0
+    for a, b in zip(serial, batched):
+        if span(a) == span(b):  # a session pads shorter plans to the common makespan: that is a different (longer) QP
+            assert abs(cost(a) - cost(b)) < 1e-5 * max(1.0, cost(a))
+            same += 1
+        assert ratio(a) >= 1.0 and ratio(b) >= 1.0
+    assert same >= 1
