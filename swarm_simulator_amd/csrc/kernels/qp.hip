@@ -661,7 +661,8 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds) {
                 out[(size_t)e * lb + f] = acc;
             }
     }
-    if (d.nj > 1 && nk > 36) {  // the wave-register path builds its coupling rows from Ek directly (coupling_row)
+    // the wave-register path and the LDS-resident tiled path build their coupling blocks from Ek directly
+    if (d.nj > 1 && nk > 36 && 3 * lb * (lb + 2) > c.lds_avail) {
         const size_t noff = (size_t)(d.nj - 1) * lb * lb;
         for (size_t it = threadIdx.x; it < noff; it += QP_THREADS) {
             const int j = (int)(it / ((size_t)lb * lb)) + 1;  // couples knot j (cols) and j+1 (rows)
@@ -1249,77 +1250,124 @@ __device__ __forceinline__ void tile_sub(double* C, int ldc, const d4& acc, int 
     for (int r = 0; r < 4; ++r) C[(size_t)(g + 4 * r) * ldc + i] -= acc[r];
 }
 
-__device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag) {
-    const int ld = d.ldb, NT = ld / 16, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// one knot of the tiled factorisation: A (ld x ld, lower) <- chol(A - B B'), C <- C A^{-T}.  A, B, C may live in global
+// memory or in LDS (generic pointers; leading dimension ld doubles, order 16*NT)
+__device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, double* C, int ld, int NT, int* flag) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int NW = QP_THREADS / 64;
-    if (tid == 0) *flag = 0;
-    __syncthreads();
-    for (int j = 0; j < d.nj; ++j) {
-        double* A = w.Td + (size_t)j * ld * ld;
-        const double* B = j > 0 ? w.To + (size_t)(j - 1) * ld * ld : nullptr;
-        double* C = j + 1 < d.nj ? w.To + (size_t)j * ld * ld : nullptr;
-        for (int p = 0; p < NT; ++p) {
-            const int nA = NT - p, nC = (C && p > 0) ? NT : 0;
-            if (B || p > 0) {
-                for (int t = wave; t < nA + nC; t += NW) {
-                    d4 acc = d4{0, 0, 0, 0};
-                    const double* Ap = A + (size_t)p * 16 * ld;
-                    if (t < nA) {
-                        const int ti = p + t;
-                        if (B) tile_nt(acc, B + (size_t)ti * 16 * ld, ld, B + (size_t)p * 16 * ld, ld, ld, lane);
-                        if (p > 0) tile_nt(acc, A + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
-                        tile_sub(A + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
-                    } else {
-                        const int ti = t - nA;
-                        tile_nt(acc, C + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
-                        tile_sub(C + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
-                    }
-                }
-                __threadfence_block();
-                __syncthreads();
-            }
-            // diagonal tile: every wave factors its own register copy (lane&15 = row)
-            double a[16];
-            {
-                const double* dp = A + (size_t)(16 * p + (lane & 15)) * ld + 16 * p;
-                const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
-            }
-            const bool ok = chol_rows<16>(a);
-            if (!ok && tid == 0) *flag = 1;
-            // rows below in A, all rows of C:  x <- x L_pp^{-T}
-            const int nbelow = ld - 16 * (p + 1), total = nbelow + (C ? ld : 0);
-            for (int base = 0; base < total; base += QP_THREADS) {
-                const int idx = base + tid;
-                const bool act = idx < total;
-                double* rp = !act ? A : (idx < nbelow ? A + (size_t)(16 * (p + 1) + idx) * ld + 16 * p : C + (size_t)(idx - nbelow) * ld + 16 * p);
-                double x[16];
-                const d4 v0 = ld4(rp), v1 = ld4(rp + 4), v2 = ld4(rp + 8), v3 = ld4(rp + 12);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = v0[k], x[4 + k] = v1[k], x[8 + k] = v2[k], x[12 + k] = v3[k];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    double sv = x[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) sv -= x[k] * rl(a[k], c);
-                    x[c] = sv / rl(a[c], c);
-                }
-                if (act) {
-                    *reinterpret_cast<d4*>(rp) = d4{x[0], x[1], x[2], x[3]};
-                    *reinterpret_cast<d4*>(rp + 4) = d4{x[4], x[5], x[6], x[7]};
-                    *reinterpret_cast<d4*>(rp + 8) = d4{x[8], x[9], x[10], x[11]};
-                    *reinterpret_cast<d4*>(rp + 12) = d4{x[12], x[13], x[14], x[15]};
+    const int n = 16 * NT;
+    for (int p = 0; p < NT; ++p) {
+        const int nA = NT - p, nC = (C && p > 0) ? NT : 0;
+        if (B || p > 0) {
+            for (int t = wave; t < nA + nC; t += NW) {
+                d4 acc = d4{0, 0, 0, 0};
+                const double* Ap = A + (size_t)p * 16 * ld;
+                if (t < nA) {
+                    const int ti = p + t;
+                    if (B) tile_nt(acc, B + (size_t)ti * 16 * ld, ld, B + (size_t)p * 16 * ld, ld, n, lane);
+                    if (p > 0) tile_nt(acc, A + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                    tile_sub(A + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
+                } else {
+                    const int ti = t - nA;
+                    tile_nt(acc, C + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                    tile_sub(C + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
                 }
             }
             __threadfence_block();
             __syncthreads();
-            if (*flag) return false;
-            if (wave == 0 && lane < 16) {  // nobody reads the diagonal tile again during the factorisation
-                double* dp = A + (size_t)(16 * p + lane) * ld + 16 * p;
+        }
+        // diagonal tile: every wave factors its own register copy (lane&15 = row)
+        double a[16];
+        {
+            const double* dp = A + (size_t)(16 * p + (lane & 15)) * ld + 16 * p;
+            const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) dp[k] = k <= lane ? a[k] : 0.0;
+            for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
+        }
+        const bool ok = chol_rows<16>(a);
+        if (!ok && tid == 0) *flag = 1;
+        double dgl = 1.0;  // reciprocal of this lane's diagonal entry: the row solves below multiply instead of dividing
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dgl = ((lane & 15) == k) ? a[k] : dgl;
+        const double inv = 1.0 / dgl;
+        // rows below in A, all rows of C:  x <- x L_pp^{-T}
+        const int nbelow = n - 16 * (p + 1), total = nbelow + (C ? n : 0);
+        for (int base = 0; base < total; base += QP_THREADS) {
+            const int idx = base + tid;
+            const bool act = idx < total;
+            double* rp = !act ? A : (idx < nbelow ? A + (size_t)(16 * (p + 1) + idx) * ld + 16 * p : C + (size_t)(idx - nbelow) * ld + 16 * p);
+            double x[16];
+            const d4 v0 = ld4(rp), v1 = ld4(rp + 4), v2 = ld4(rp + 8), v3 = ld4(rp + 12);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = v0[k], x[4 + k] = v1[k], x[8 + k] = v2[k], x[12 + k] = v3[k];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double sv = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sv -= x[k] * rl(a[k], c);
+                x[c] = sv * rl(inv, c);
             }
+            if (act) {
+                *reinterpret_cast<d4*>(rp) = d4{x[0], x[1], x[2], x[3]};
+                *reinterpret_cast<d4*>(rp + 4) = d4{x[4], x[5], x[6], x[7]};
+                *reinterpret_cast<d4*>(rp + 8) = d4{x[8], x[9], x[10], x[11]};
+                *reinterpret_cast<d4*>(rp + 12) = d4{x[12], x[13], x[14], x[15]};
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (*flag) return false;
+        if (wave == 0 && lane < 16) {  // nobody reads the diagonal tile again during the factorisation
+            double* dp = A + (size_t)(16 * p + lane) * ld + 16 * p;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dp[k] = k <= lane ? a[k] : 0.0;
+        }
+    }
+    return true;
+}
+
+__device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag, double* lds, int lds_avail) {
+    const int ld = d.ldb, NT = ld / 16, tid = threadIdx.x;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    const int ldl = ld + 2;  // LDS leading dimension: rows 16 apart fall into different banks
+    if (3 * ld * ldl <= lds_avail) {
+        // LDS-resident variant (nk <= 72): the three blocks of a knot stay in LDS, every dependent step of the panel
+        // loop is an LDS round trip instead of an L2 one.  T_{j+1,j} is generated in place from Ek (it is 3x3-block
+        // diagonal), L_{j,j-1} is the previous knot's C buffer.
+        double* bufA = lds;
+        double* bufB = lds + (size_t)ld * ldl;
+        double* bufC = lds + 2 * (size_t)ld * ldl;
+        for (int j = 0; j < d.nj; ++j) {
+            const double* Ag = w.Td + (size_t)j * ld * ld;
+            for (int it = tid; it < ld * ld; it += QP_THREADS) bufA[(it / ld) * ldl + it % ld] = Ag[it];
+            const bool hasC = j + 1 < d.nj;
+            if (hasC) {
+                const double* E = w.Ek + 9 * (j + 1);
+                for (int it = tid; it < ld * ld; it += QP_THREADS) {
+                    const int rr = it / ld, cc = it % ld;
+                    bufC[rr * ldl + cc] = (rr / 3 == cc / 3 && rr < d.nk && cc < d.nk) ? E[3 * (cc % 3) + (rr % 3)] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (!factor_knot_tiled(bufA, j > 0 ? bufB : nullptr, hasC ? bufC : nullptr, ldl, NT, flag)) return false;
+            __syncthreads();  // the diagonal tiles are written late by wave 0
+            double* Aw = w.Td + (size_t)j * ld * ld;
+            for (int it = tid; it < ld * ld; it += QP_THREADS) Aw[it] = bufA[(it / ld) * ldl + it % ld];
+            if (hasC) {
+                double* Cw = w.To + (size_t)j * ld * ld;
+                for (int it = tid; it < ld * ld; it += QP_THREADS) Cw[it] = bufC[(it / ld) * ldl + it % ld];
+            }
+            double* t = bufB;
+            bufB = bufC, bufC = t;
+            __syncthreads();
+        }
+    } else {
+        for (int j = 0; j < d.nj; ++j) {
+            double* A = w.Td + (size_t)j * ld * ld;
+            const double* B = j > 0 ? w.To + (size_t)(j - 1) * ld * ld : nullptr;
+            double* C = j + 1 < d.nj ? w.To + (size_t)j * ld * ld : nullptr;
+            if (!factor_knot_tiled(A, B, C, ld, NT, flag)) return false;
         }
     }
     __threadfence_block();
@@ -1328,24 +1376,27 @@ __device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag) {
 }
 
 // v <- L^{-1} v for one knot block (wave 0; v in LDS, ld entries)
-__device__ __forceinline__ void trisolve_fwd(const double* L, int ld, double* v, int lane) {
-    const int NT = ld / 16, i = lane & 15;
+__device__ __forceinline__ void trisolve_fwd(const double* L, int ld, int n, double* v, int lane) {
+    const int NT = n / 16, i = lane & 15;
     for (int p = 0; p < NT; ++p) {
         double a[16];
         const double* dp = L + (size_t)(16 * p + i) * ld + 16 * p;
         const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
-        double x = v[16 * p + i];
+        double x = v[16 * p + i], dgl = 1.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dgl = (i == k) ? a[k] : dgl;
+        const double inv = 1.0 / dgl;  // one division per tile instead of one per dependent step
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const double xc = rl(x, c) / rl(a[c], c);
+            const double xc = rl(x, c) * rl(inv, c);
             x = (i == c) ? xc : (i > c ? x - a[c] * xc : x);
         }
         if (lane < 16) v[16 * p + i] = x;
-        for (int r0 = 16 * (p + 1); r0 < ld; r0 += 64) {
+        for (int r0 = 16 * (p + 1); r0 < n; r0 += 64) {
             const int r = r0 + lane;
-            const bool act = r < ld;
+            const bool act = r < n;
             const double* rp = L + (size_t)(act ? r : 0) * ld + 16 * p;
             const d4 u0 = ld4(rp), u1 = ld4(rp + 4), u2 = ld4(rp + 8), u3 = ld4(rp + 12);
             double sv = 0;
@@ -1360,16 +1411,19 @@ __device__ __forceinline__ void trisolve_fwd(const double* L, int ld, double* v,
 }
 
 // v <- L^{-T} v
-__device__ __forceinline__ void trisolve_bwd(const double* L, int ld, double* v, int lane) {
-    const int NT = ld / 16, i = lane & 15;
+__device__ __forceinline__ void trisolve_bwd(const double* L, int ld, int n, double* v, int lane) {
+    const int NT = n / 16, i = lane & 15;
     for (int p = NT - 1; p >= 0; --p) {
         double at[16];  // column i of the diagonal tile
 #pragma unroll
         for (int k = 0; k < 16; ++k) at[k] = L[(size_t)(16 * p + k) * ld + 16 * p + i];
-        double x = v[16 * p + i];
+        double x = v[16 * p + i], dgl = 1.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dgl = (i == k) ? at[k] : dgl;
+        const double inv = 1.0 / dgl;
 #pragma unroll
         for (int c = 15; c >= 0; --c) {
-            const double xc = rl(x, c) / rl(at[c], c);
+            const double xc = rl(x, c) * rl(inv, c);
             x = (i == c) ? xc : (i < c ? x - at[c] * xc : x);
         }
         if (lane < 16) v[16 * p + i] = x;
@@ -1388,11 +1442,16 @@ __device__ __forceinline__ void trisolve_bwd(const double* L, int ld, double* v,
 }
 
 // solve T du = rhs in place (rhs in global, nk per knot).  lds: 2*ld vector buffers + QP_THREADS partial sums.
-__device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
+__device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double* lds, int lds_avail) {
     const int nk = d.nk, ld = d.ldb, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* cur = lds;
     double* oth = lds + ld;
     double* part = lds + 2 * ld;
+    // small blocks: the diagonal factor of the knot is staged in LDS (coalesced copy by all threads) so that the tile-by-
+    // tile triangular solve of wave 0 is a chain of LDS round trips, not L2 ones
+    const int ldl = ld + 2;
+    double* Lst = part + QP_THREADS;
+    const bool staged = 2 * ld + QP_THREADS + ld * ldl <= lds_avail;
     for (int j = 0; j < d.nj; ++j) {  // forward: v_j <- L_jj^{-1} (v_j - L_{j,j-1} v_{j-1})
         for (int r = tid; r < ld; r += QP_THREADS) cur[r] = r < nk ? rhs[(size_t)j * nk + r] : 0.0;
         __syncthreads();
@@ -1409,7 +1468,12 @@ __device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double*
             }
             __syncthreads();
         }
-        if (wave == 0) trisolve_fwd(w.Td + (size_t)j * ld * ld, ld, cur, lane);
+        if (staged) {
+            const double* Lg = w.Td + (size_t)j * ld * ld;
+            for (int it = tid; it < ld * ld; it += QP_THREADS) Lst[(it / ld) * ldl + it % ld] = Lg[it];
+            __syncthreads();
+        }
+        if (wave == 0) trisolve_fwd(staged ? Lst : w.Td + (size_t)j * ld * ld, staged ? ldl : ld, ld, cur, lane);
         __syncthreads();
         for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
         double* t = cur;
@@ -1444,7 +1508,12 @@ __device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double*
             }
             __syncthreads();
         }
-        if (wave == 0) trisolve_bwd(w.Td + (size_t)j * ld * ld, ld, cur, lane);
+        if (staged) {
+            const double* Lg = w.Td + (size_t)j * ld * ld;
+            for (int it = tid; it < ld * ld; it += QP_THREADS) Lst[(it / ld) * ldl + it % ld] = Lg[it];
+            __syncthreads();
+        }
+        if (wave == 0) trisolve_bwd(staged ? Lst : w.Td + (size_t)j * ld * ld, staged ? ldl : ld, ld, cur, lane);
         __syncthreads();
         for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
         double* t = cur;
@@ -1467,7 +1536,7 @@ __device__ void init_block_pads(const QpDims& d, const QpWs& w) {
     }
 }
 
-__device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag) {
+__device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag, int lds_avail) {
     if (d.nk <= 36) {
         switch (d.nk) {
             case 9: return twisted_factor<9>(d, w, flag, lA);
@@ -1476,10 +1545,10 @@ __device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, 
             default: return twisted_factor<36>(d, w, flag, lA);
         }
     }
-    return factor_tiled(d, w, flag);
+    return factor_tiled(d, w, flag, lA, lds_avail);
 }
 
-__device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA) {
+__device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA, int lds_avail) {
     if (d.nk <= 36) {
         switch (d.nk) {  // lA = start of the dynamic LDS region (the three block buffers are free between factorisations)
             case 9: solve_staged<9>(d, w, rhs, lA); break;
@@ -1489,7 +1558,7 @@ __device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, d
         }
         return;
     }
-    solve_tiled(d, w, rhs, lA);
+    solve_tiled(d, w, rhs, lA, lds_avail);
 }
 
 
@@ -1497,7 +1566,7 @@ __device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, d
 // allocation (the wave-register path wants every VGPR) then neither depends on nor disturbs the row sweeps around them,
 // and no kernel-level struct has its address taken.
 struct BlkArgs {
-    int nk, nj, ldb;
+    int nk, nj, ldb, lds_avail;
     double *Td, *To, *Lf;
     double* Ek;
 };
@@ -1511,13 +1580,13 @@ __device__ __noinline__ bool factor_entry(BlkArgs b, double* lds, int* flag) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    return factor_dispatch(d, w, lds, flag);
+    return factor_dispatch(d, w, lds, flag, b.lds_avail);
 }
 __device__ __noinline__ void solve_entry(BlkArgs b, double* rhs, double* lds) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch(d, w, rhs, lds);
+    solve_dispatch(d, w, rhs, lds, b.lds_avail);
 }
 
 #define QP_POLISH_PART 2
@@ -1573,7 +1642,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     int* flag = (int*)(lds_raw + 16);
     double* lds = lds_raw + 32;
     double* lA = lds;
-    const BlkArgs ba{d.nk, d.nj, d.ldb, w.Td, w.To, w.Lf, w.Ek};
+    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek};
     double* red2 = red;
     int* flag2 = flag;
 
@@ -2113,6 +2182,10 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
         lds = std::max(lds, sizeof(double) * ((size_t)4 * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
+        if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
+            const size_t lb = (size_t)((nk + 15) & ~15);
+            lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
+        }
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (s.p.iteration > 0)
             hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
