@@ -289,6 +289,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// 1/sqrt(x): v_rsq_f64 plus two Newton steps (full double precision for normal x > 0); an IEEE sqrt followed by an IEEE
+// division is ~6x the instructions and sits on the dependent chain of every Cholesky column
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
 template <int PASS>
 __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, size_t r, const QpWs& w, PassIO& io,
                                        double& wgt, double& v) {
@@ -781,13 +791,16 @@ __device__ __forceinline__ void syrk_rows(double (&a)[NK], const double (&b)[NK]
 }
 
 template <int NK>
-__device__ __forceinline__ bool chol_rows(double (&a)[NK]) {  // right-looking; a[c] = L[r][c] for lanes r >= c
-    bool ok = true;
+__device__ __forceinline__ bool chol_rows(double (&a)[NK], double& dinv) {  // right-looking; a[c] = L[r][c] for lanes r >= c
+    bool ok = true;                                                           // dinv: 1 / L[r][r] of this lane's row
+    const int r = threadIdx.x & 63;
+    dinv = 1.0;
 #pragma unroll
     for (int c = 0; c < NK; ++c) {
         const double dcc = rl(a[c], c);
         if (!(dcc > 0)) ok = false;
-        const double inv = 1.0 / sqrt(dcc);
+        const double inv = fast_rsqrt(dcc);
+        dinv = (r == c) ? inv : dinv;
         a[c] *= inv;
 #pragma unroll
         for (int k = c + 1; k < NK; ++k) a[k] -= a[c] * rl(a[c], k);
@@ -837,16 +850,15 @@ __device__ __forceinline__ void syrk_tiles_lo(double* ldsW, int lane, bool accum
 
 // factor row a (lane rr) -> global Lf block [k][r] and LDS row-major copy + reciprocal diagonal
 template <int NK>
-__device__ __forceinline__ void park_factor(const double (&a)[NK], double* L0, double* ldsL, double* ldsInv, int r, bool act) {
+__device__ __forceinline__ void park_factor(const double (&a)[NK], double dinv, double* L0, double* ldsL, double* ldsInv, int r,
+                                            bool act) {
     if (act) {
-        double dg = 1.0;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             L0[k * NK + r] = k <= r ? a[k] : 0.0;
             ldsL[r * WF_LDL + k] = a[k];
-            dg = (r == k) ? a[k] : dg;
         }
-        ldsInv[r] = 1.0 / dg;
+        ldsInv[r] = dinv;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -896,9 +908,10 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if (!chol_rows<NK>(a)) ok = false;
+        double dinv;
+        if (!chol_rows<NK>(a, dinv)) ok = false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
-        park_factor<NK>(a, L0, ldsL, ldsInv, r, act);
+        park_factor<NK>(a, dinv, L0, ldsL, ldsInv, r, act);
         {
             double x[NK];
             coupling_solve_lo<NK>(w, j, dir, rr, ldsL, ldsInv, x);
@@ -940,7 +953,8 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];
     }
-    if (!chol_rows<NK>(a)) return false;
+    double dinv;
+    if (!chol_rows<NK>(a, dinv)) return false;
     double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
     if (act) {
 #pragma unroll
@@ -963,7 +977,8 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
         if (i > 0) syrk_rows<NK>(a, b, ldsW, r, rr);
-        if (!chol_rows<NK>(a)) return false;
+        double dinv;
+        if (!chol_rows<NK>(a, dinv)) return false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         if (act) {
 #pragma unroll
@@ -973,7 +988,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
         coupling_row<NK>(w, j, dir, rr, b);
 #pragma unroll
         for (int c = 0; c < NK; ++c) {
-            const double xc = b[c] / rl(a[c], c);
+            const double xc = b[c] * rl(dinv, c);  // reciprocal diagonal from the Cholesky: no division on the chain
             b[c] = xc;
 #pragma unroll
             for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
@@ -1007,7 +1022,8 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
         for (int k = 0; k < NK; ++k) b[k] = Cm[k * NK + rr];
         syrk_rows<NK>(a, b, ldsW, r, rr);
     }
-    if (!chol_rows<NK>(a)) return false;
+    double dinv;
+    if (!chol_rows<NK>(a, dinv)) return false;
     double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
     if (act) {
 #pragma unroll
@@ -1140,7 +1156,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 double dg = 1.0;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-                const double inv = 1.0 / dg;
+                const double inv = fast_rcp(dg);
 #pragma unroll
                 for (int c = 0; c < NK; ++c) {
                     const double xc = rl(v, c) * rl(inv, c);
@@ -1186,7 +1202,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 double dg = 1.0;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-                const double inv = 1.0 / dg;
+                const double inv = fast_rcp(dg);
                 if (fwd) {
 #pragma unroll
                     for (int c = 0; c < NK; ++c) {
@@ -1227,15 +1243,42 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
 //   substitutions: block matvecs by the whole workgroup, the triangular solves by wave 0 tile by tile.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ d4 ld4(const double* p) { return *reinterpret_cast<const d4*>(p); }
+// memory helpers of the tiled path: LDS = true turns the generic pointer into an LDS one (ds_read/ds_write instead of flat)
+#define AS_LDS __attribute__((address_space(3)))
+template <bool LDS>
+__device__ __forceinline__ d4 ld4T(const double* p) {
+    if (LDS) return *(const AS_LDS d4*)(p);
+    return *reinterpret_cast<const d4*>(p);
+}
+template <bool LDS>
+__device__ __forceinline__ double ldT(const double* p) {
+    if (LDS) return *(const AS_LDS double*)(p);
+    return *p;
+}
+template <bool LDS>
+__device__ __forceinline__ void stT(double* p, double v) {
+    if (LDS)
+        *(AS_LDS double*)(p) = v;
+    else
+        *p = v;
+}
+template <bool LDS>
+__device__ __forceinline__ void st4T(double* p, d4 v) {
+    if (LDS)
+        *(AS_LDS d4*)(p) = v;
+    else
+        *reinterpret_cast<d4*>(p) = v;
+}
 
 // acc += X(16 x K) Y(16 x K)'   (X, Y row-major, K a multiple of 16).  Lane (i = l&15, g = l>>4) loads X[i][k0+4g .. +3]:
 // the four MFMA steps of a 16-chunk use k = 4g + s on both operands, a permutation of the summation index.
+template <bool LDS>
 __device__ __forceinline__ void tile_nt(d4& acc, const double* X, int ldx, const double* Y, int ldy, int K, int lane) {
     const int i = lane & 15, g = lane >> 4;
     const double* xp = X + (size_t)i * ldx + 4 * g;
     const double* yp = Y + (size_t)i * ldy + 4 * g;
     for (int k0 = 0; k0 < K; k0 += 16) {
-        const d4 xa = ld4(xp + k0), yb = ld4(yp + k0);
+        const d4 xa = ld4T<LDS>(xp + k0), yb = ld4T<LDS>(yp + k0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], yb[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], yb[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], yb[2], acc, 0, 0, 0);
@@ -1244,14 +1287,38 @@ __device__ __forceinline__ void tile_nt(d4& acc, const double* X, int ldx, const
 }
 
 // C(16x16) -= acc   (C/D layout: row = (l>>4) + 4*reg, col = l&15)
+template <bool LDS>
 __device__ __forceinline__ void tile_sub(double* C, int ldc, const d4& acc, int lane) {
     const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C[(size_t)(g + 4 * r) * ldc + i] -= acc[r];
+    for (int r = 0; r < 4; ++r) {
+        double* cp = C + (size_t)(g + 4 * r) * ldc + i;
+        stT<LDS>(cp, ldT<LDS>(cp) - acc[r]);
+    }
+}
+
+// global (ld x ld, dense) -> LDS (leading dimension ldl): all loads of a thread are issued before its LDS stores, so the
+// copy costs one memory round trip, not one per element
+__device__ __forceinline__ void stage_block(double* dst, int ldl, const double* src, int ld) {
+    const int total = ld * ld;
+    for (int base = threadIdx.x; base < total; base += 8 * QP_THREADS) {
+        double tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = base + u * QP_THREADS;
+            tmp[u] = it < total ? src[it] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = base + u * QP_THREADS;
+            if (it < total) *(AS_LDS double*)(dst + (it / ld) * ldl + it % ld) = tmp[u];
+        }
+    }
 }
 
 // one knot of the tiled factorisation: A (ld x ld, lower) <- chol(A - B B'), C <- C A^{-T}.  A, B, C may live in global
 // memory or in LDS (generic pointers; leading dimension ld doubles, order 16*NT)
+template <bool LDS>
 __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, double* C, int ld, int NT, int* flag) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int NW = QP_THREADS / 64;
@@ -1264,13 +1331,13 @@ __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, do
                 const double* Ap = A + (size_t)p * 16 * ld;
                 if (t < nA) {
                     const int ti = p + t;
-                    if (B) tile_nt(acc, B + (size_t)ti * 16 * ld, ld, B + (size_t)p * 16 * ld, ld, n, lane);
-                    if (p > 0) tile_nt(acc, A + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
-                    tile_sub(A + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
+                    if (B) tile_nt<LDS>(acc, B + (size_t)ti * 16 * ld, ld, B + (size_t)p * 16 * ld, ld, n, lane);
+                    if (p > 0) tile_nt<LDS>(acc, A + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                    tile_sub<LDS>(A + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
                 } else {
                     const int ti = t - nA;
-                    tile_nt(acc, C + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
-                    tile_sub(C + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
+                    tile_nt<LDS>(acc, C + (size_t)ti * 16 * ld, ld, Ap, ld, 16 * p, lane);
+                    tile_sub<LDS>(C + (size_t)ti * 16 * ld + 16 * p, ld, acc, lane);
                 }
             }
             __threadfence_block();
@@ -1280,16 +1347,13 @@ __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, do
         double a[16];
         {
             const double* dp = A + (size_t)(16 * p + (lane & 15)) * ld + 16 * p;
-            const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
+            const d4 v0 = ld4T<LDS>(dp), v1 = ld4T<LDS>(dp + 4), v2 = ld4T<LDS>(dp + 8), v3 = ld4T<LDS>(dp + 12);
 #pragma unroll
             for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
         }
-        const bool ok = chol_rows<16>(a);
+        double inv;  // reciprocal of this lane's diagonal entry: the row solves below multiply instead of dividing
+        const bool ok = chol_rows<16>(a, inv);
         if (!ok && tid == 0) *flag = 1;
-        double dgl = 1.0;  // reciprocal of this lane's diagonal entry: the row solves below multiply instead of dividing
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dgl = ((lane & 15) == k) ? a[k] : dgl;
-        const double inv = 1.0 / dgl;
         // rows below in A, all rows of C:  x <- x L_pp^{-T}
         const int nbelow = n - 16 * (p + 1), total = nbelow + (C ? n : 0);
         for (int base = 0; base < total; base += QP_THREADS) {
@@ -1297,7 +1361,7 @@ __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, do
             const bool act = idx < total;
             double* rp = !act ? A : (idx < nbelow ? A + (size_t)(16 * (p + 1) + idx) * ld + 16 * p : C + (size_t)(idx - nbelow) * ld + 16 * p);
             double x[16];
-            const d4 v0 = ld4(rp), v1 = ld4(rp + 4), v2 = ld4(rp + 8), v3 = ld4(rp + 12);
+            const d4 v0 = ld4T<LDS>(rp), v1 = ld4T<LDS>(rp + 4), v2 = ld4T<LDS>(rp + 8), v3 = ld4T<LDS>(rp + 12);
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = v0[k], x[4 + k] = v1[k], x[8 + k] = v2[k], x[12 + k] = v3[k];
 #pragma unroll
@@ -1308,10 +1372,10 @@ __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, do
                 x[c] = sv * rl(inv, c);
             }
             if (act) {
-                *reinterpret_cast<d4*>(rp) = d4{x[0], x[1], x[2], x[3]};
-                *reinterpret_cast<d4*>(rp + 4) = d4{x[4], x[5], x[6], x[7]};
-                *reinterpret_cast<d4*>(rp + 8) = d4{x[8], x[9], x[10], x[11]};
-                *reinterpret_cast<d4*>(rp + 12) = d4{x[12], x[13], x[14], x[15]};
+                st4T<LDS>(rp, d4{x[0], x[1], x[2], x[3]});
+                st4T<LDS>(rp + 4, d4{x[4], x[5], x[6], x[7]});
+                st4T<LDS>(rp + 8, d4{x[8], x[9], x[10], x[11]});
+                st4T<LDS>(rp + 12, d4{x[12], x[13], x[14], x[15]});
             }
         }
         __threadfence_block();
@@ -1320,7 +1384,7 @@ __device__ __forceinline__ bool factor_knot_tiled(double* A, const double* B, do
         if (wave == 0 && lane < 16) {  // nobody reads the diagonal tile again during the factorisation
             double* dp = A + (size_t)(16 * p + lane) * ld + 16 * p;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) dp[k] = k <= lane ? a[k] : 0.0;
+            for (int k = 0; k < 16; ++k) stT<LDS>(dp + k, k <= lane ? a[k] : 0.0);
         }
     }
     return true;
@@ -1340,7 +1404,7 @@ __device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag, double* 
         double* bufC = lds + 2 * (size_t)ld * ldl;
         for (int j = 0; j < d.nj; ++j) {
             const double* Ag = w.Td + (size_t)j * ld * ld;
-            for (int it = tid; it < ld * ld; it += QP_THREADS) bufA[(it / ld) * ldl + it % ld] = Ag[it];
+            stage_block(bufA, ldl, Ag, ld);
             const bool hasC = j + 1 < d.nj;
             if (hasC) {
                 const double* E = w.Ek + 9 * (j + 1);
@@ -1350,7 +1414,7 @@ __device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag, double* 
                 }
             }
             __syncthreads();
-            if (!factor_knot_tiled(bufA, j > 0 ? bufB : nullptr, hasC ? bufC : nullptr, ldl, NT, flag)) return false;
+            if (!factor_knot_tiled<true>(bufA, j > 0 ? bufB : nullptr, hasC ? bufC : nullptr, ldl, NT, flag)) return false;
             __syncthreads();  // the diagonal tiles are written late by wave 0
             double* Aw = w.Td + (size_t)j * ld * ld;
             for (int it = tid; it < ld * ld; it += QP_THREADS) Aw[it] = bufA[(it / ld) * ldl + it % ld];
@@ -1367,7 +1431,7 @@ __device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag, double* 
             double* A = w.Td + (size_t)j * ld * ld;
             const double* B = j > 0 ? w.To + (size_t)(j - 1) * ld * ld : nullptr;
             double* C = j + 1 < d.nj ? w.To + (size_t)j * ld * ld : nullptr;
-            if (!factor_knot_tiled(A, B, C, ld, NT, flag)) return false;
+            if (!factor_knot_tiled<false>(A, B, C, ld, NT, flag)) return false;
         }
     }
     __threadfence_block();
@@ -1376,12 +1440,13 @@ __device__ bool factor_tiled(const QpDims& d, const QpWs& w, int* flag, double* 
 }
 
 // v <- L^{-1} v for one knot block (wave 0; v in LDS, ld entries)
+template <bool LDS>
 __device__ __forceinline__ void trisolve_fwd(const double* L, int ld, int n, double* v, int lane) {
     const int NT = n / 16, i = lane & 15;
     for (int p = 0; p < NT; ++p) {
         double a[16];
         const double* dp = L + (size_t)(16 * p + i) * ld + 16 * p;
-        const d4 v0 = ld4(dp), v1 = ld4(dp + 4), v2 = ld4(dp + 8), v3 = ld4(dp + 12);
+        const d4 v0 = ld4T<LDS>(dp), v1 = ld4T<LDS>(dp + 4), v2 = ld4T<LDS>(dp + 8), v3 = ld4T<LDS>(dp + 12);
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = v0[k], a[4 + k] = v1[k], a[8 + k] = v2[k], a[12 + k] = v3[k];
         double x = v[16 * p + i], dgl = 1.0;
@@ -1398,7 +1463,7 @@ __device__ __forceinline__ void trisolve_fwd(const double* L, int ld, int n, dou
             const int r = r0 + lane;
             const bool act = r < n;
             const double* rp = L + (size_t)(act ? r : 0) * ld + 16 * p;
-            const d4 u0 = ld4(rp), u1 = ld4(rp + 4), u2 = ld4(rp + 8), u3 = ld4(rp + 12);
+            const d4 u0 = ld4T<LDS>(rp), u1 = ld4T<LDS>(rp + 4), u2 = ld4T<LDS>(rp + 8), u3 = ld4T<LDS>(rp + 12);
             double sv = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1411,12 +1476,13 @@ __device__ __forceinline__ void trisolve_fwd(const double* L, int ld, int n, dou
 }
 
 // v <- L^{-T} v
+template <bool LDS>
 __device__ __forceinline__ void trisolve_bwd(const double* L, int ld, int n, double* v, int lane) {
     const int NT = n / 16, i = lane & 15;
     for (int p = NT - 1; p >= 0; --p) {
         double at[16];  // column i of the diagonal tile
 #pragma unroll
-        for (int k = 0; k < 16; ++k) at[k] = L[(size_t)(16 * p + k) * ld + 16 * p + i];
+        for (int k = 0; k < 16; ++k) at[k] = ldT<LDS>(L + (size_t)(16 * p + k) * ld + 16 * p + i);
         double x = v[16 * p + i], dgl = 1.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) dgl = (i == k) ? at[k] : dgl;
@@ -1433,7 +1499,7 @@ __device__ __forceinline__ void trisolve_bwd(const double* L, int ld, int n, dou
             const double* cp = L + (size_t)(16 * p) * ld + (act ? k : 0);
             double sv = 0;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) sv += cp[(size_t)c * ld] * rl(x, c);
+            for (int c = 0; c < 16; ++c) sv += ldT<LDS>(cp + (size_t)c * ld) * rl(x, c);
             if (act) v[k] -= sv;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1469,11 +1535,15 @@ __device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double*
             __syncthreads();
         }
         if (staged) {
-            const double* Lg = w.Td + (size_t)j * ld * ld;
-            for (int it = tid; it < ld * ld; it += QP_THREADS) Lst[(it / ld) * ldl + it % ld] = Lg[it];
+            stage_block(Lst, ldl, w.Td + (size_t)j * ld * ld, ld);
             __syncthreads();
         }
-        if (wave == 0) trisolve_fwd(staged ? Lst : w.Td + (size_t)j * ld * ld, staged ? ldl : ld, ld, cur, lane);
+        if (wave == 0) {
+            if (staged)
+                trisolve_fwd<true>(Lst, ldl, ld, cur, lane);
+            else
+                trisolve_fwd<false>(w.Td + (size_t)j * ld * ld, ld, ld, cur, lane);
+        }
         __syncthreads();
         for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
         double* t = cur;
@@ -1509,11 +1579,15 @@ __device__ void solve_tiled(const QpDims& d, const QpWs& w, double* rhs, double*
             __syncthreads();
         }
         if (staged) {
-            const double* Lg = w.Td + (size_t)j * ld * ld;
-            for (int it = tid; it < ld * ld; it += QP_THREADS) Lst[(it / ld) * ldl + it % ld] = Lg[it];
+            stage_block(Lst, ldl, w.Td + (size_t)j * ld * ld, ld);
             __syncthreads();
         }
-        if (wave == 0) trisolve_bwd(staged ? Lst : w.Td + (size_t)j * ld * ld, staged ? ldl : ld, ld, cur, lane);
+        if (wave == 0) {
+            if (staged)
+                trisolve_bwd<true>(Lst, ldl, ld, cur, lane);
+            else
+                trisolve_bwd<false>(w.Td + (size_t)j * ld * ld, ld, ld, cur, lane);
+        }
         __syncthreads();
         for (int r = tid; r < nk; r += QP_THREADS) rhs[(size_t)j * nk + r] = cur[r];
         double* t = cur;
