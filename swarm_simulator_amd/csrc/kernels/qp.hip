@@ -1141,10 +1141,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * STG, tid - 128, QP_THREADS - 128);
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours, then backward
-                double a[NK];
                 double v = vec[mid * NK + rr];
-#pragma unroll
-                for (int k = 0; k < NK; ++k) a[k] = DG_ROW(buf + O_LD, k);
+                const double* dgm = buf + O_LD;
                 if (mid > 0) {
 #pragma unroll
                     for (int k = 0; k < NK; ++k) v -= buf[O_LO + k * LDP + rr] * vec[(mid - 1) * NK + k];
@@ -1153,21 +1151,16 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
 #pragma unroll
                     for (int k = 0; k < NK; ++k) v -= buf[O_RO + k * LDP + rr] * vec[(mid + 1) * NK + k];
                 }
-                double dg = 1.0;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-                const double inv = fast_rcp(dg);
+                const double inv = fast_rcp(dgm[rr * NK - rr * (rr - 1) / 2]);
 #pragma unroll
                 for (int c = 0; c < NK; ++c) {
                     const double xc = rl(v, c) * rl(inv, c);
-                    v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
+                    v = (r == c) ? xc : (r > c ? v - DG_ROW(dgm, c) * xc : v);
                 }
-#pragma unroll
-                for (int k = 0; k < NK; ++k) a[k] = DG_COL(buf + O_LD, k);  // column r
 #pragma unroll
                 for (int c = NK - 1; c >= 0; --c) {
                     const double xc = rl(v, c) * rl(inv, c);
-                    v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
+                    v = (r == c) ? xc : (r < c ? v - DG_COL(dgm, c) * xc : v);
                 }
                 if (r < NK) vec[mid * NK + r] = v;
             }
@@ -1177,20 +1170,23 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (jb >= 0) {
                 const double* dgp = buf + (wave == 0 ? O_LD : O_RD);
                 const double* bl = buf + (wave == 0 ? O_LO : O_RO);
-                double a[NK];
                 double v = vec[jb * NK + rr];
                 const bool first_bwd = !fwd && s == SF + 1;  // neighbour solution comes from the middle block (in LDS)
                 const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
+                // the factor entries are read from LDS where they are used (no 36-double row held in VGPRs: the loads do
+                // not depend on the chain and the scheduler hoists as many as the register budget allows)
+                const double inv = fast_rcp(dgp[rr * NK - rr * (rr - 1) / 2]);  // 1 / L[rr][rr]
                 if (fwd) {
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) a[k] = DG_ROW(dgp, k);
-                    if (has_nb) {  // coupling block read straight from LDS: only the diagonal row is held in VGPRs
+                    if (has_nb) {
 #pragma unroll
                         for (int k = 0; k < NK; ++k) v -= bl[k * LDP + rr] * rl(prev, k);
                     }
-                } else {
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) a[k] = DG_COL(dgp, k);
+                    for (int c = 0; c < NK; ++c) {
+                        const double xc = rl(v, c) * rl(inv, c);
+                        v = (r == c) ? xc : (r > c ? v - DG_ROW(dgp, c) * xc : v);
+                    }
+                } else {
                     if (first_bwd) {
 #pragma unroll
                         for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * vec[mid * NK + k];
@@ -1198,22 +1194,10 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
 #pragma unroll
                         for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * rl(prev, k);
                     }
-                }
-                double dg = 1.0;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) dg = (r == k) ? a[k] : dg;
-                const double inv = fast_rcp(dg);
-                if (fwd) {
-#pragma unroll
-                    for (int c = 0; c < NK; ++c) {
-                        const double xc = rl(v, c) * rl(inv, c);
-                        v = (r == c) ? xc : (r > c ? v - a[c] * xc : v);
-                    }
-                } else {
 #pragma unroll
                     for (int c = NK - 1; c >= 0; --c) {
                         const double xc = rl(v, c) * rl(inv, c);
-                        v = (r == c) ? xc : (r < c ? v - a[c] * xc : v);
+                        v = (r == c) ? xc : (r < c ? v - DG_COL(dgp, c) * xc : v);
                     }
                 }
                 prev = v;
