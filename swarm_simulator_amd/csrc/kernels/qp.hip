@@ -322,9 +322,15 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         wgt = z * fast_rcp(s + io.dreg * z);
         const double dza = wgt * (gdx_a + rg - s);
         const double dsa = -s - s * dza * iz;  // (-s z - s dza) / z
-        w.cc[r] = dsa * dza;
+        const double cc = dsa * dza;
+        w.cc[r] = cc;
         io.vmax = fmax(io.vmax, fmax(-dsa * is, -dza * iz));
-        io.sum0 += s * z, io.sum1 += s * dza + z * dsa, io.sum2 += dsa * dza;
+        io.sum0 += s * z, io.sum1 += s * dza + z * dsa, io.sum2 += cc;
+        // the corrector's right-hand side is affine in sigma*mu, which is only known after this sweep's reductions:
+        //   v_corr = -wgt (rg - (s z + cc - sigma mu) / z) = v - sigma mu * wgt / z.   Both parts are accumulated here, so
+        // the corrector needs no sweep of its own (out: v, and wgt := wgt / z)
+        v = -wgt * (rg - s - cc * iz);
+        wgt = wgt * iz;
     } else if (PASS == PASS_CORR_RHS) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
@@ -371,7 +377,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int oq = d.oq, N = d.N;
-    constexpr bool accum = (PASS == PASS_BUILD || PASS == PASS_CORR_RHS);
+    constexpr bool accum = (PASS == PASS_BUILD || PASS == PASS_CORR_RHS || PASS == PASS_AFF);
+    constexpr bool aff = (PASS == PASS_AFF);  // S[0..2] / S[3..5] then hold the two parts of the corrector rhs (see row_op)
     constexpr bool pinned_only = (PASS == PASS_PRESOLVE);
     // ---- control points of batch agents: bound + frozen rows
     const int ncp = d.nb * oq;
@@ -408,7 +415,10 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                         S[dg] += wgt;
                         gz[k] += sg * w.z[r];
                     }
-                    yv[k] += sg * v;
+                    if (aff)
+                        S[k] += sg * v, S[3 + k] += sg * wgt;
+                    else
+                        yv[k] += sg * v;
                 }
             }
         }
@@ -432,19 +442,28 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                     const double z = w.z[r];
                     gz[0] += z * n0, gz[1] += z * n1, gz[2] += z * n2;
                 }
-                yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+                if (aff) {
+                    S[0] += v * n0, S[1] += v * n1, S[2] += v * n2;
+                    S[3] += wgt * n0, S[4] += wgt * n1, S[5] += wgt * n2;
+                } else {
+                    yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+                }
             }
         }
         if (accum) {
             double* acc = w.cpacc + (size_t)it * 12;
-            if (PASS == PASS_BUILD) {
+            if (PASS == PASS_BUILD || aff) {
 #pragma unroll
                 for (int e = 0; e < 6; ++e) acc[e] = S[e];
+            }
+            if (PASS == PASS_BUILD) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) acc[9 + e] = gz[e];
             }
+            if (!aff) {
 #pragma unroll
-            for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e];
+                for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e];
+            }
         }
     }
 #ifdef QP_SWEEPSTATS
@@ -493,7 +512,12 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 const double z = w.z[r];
                 acc[9] = z * n0, acc[10] = z * n1, acc[11] = z * n2;
             }
-            acc[6] = v * n0, acc[7] = v * n1, acc[8] = v * n2;
+            if (aff) {
+                acc[0] = v * n0, acc[1] = v * n1, acc[2] = v * n2;
+                acc[3] = wgt * n0, acc[4] = wgt * n1, acc[5] = wgt * n2;
+            } else {
+                acc[6] = v * n0, acc[7] = v * n1, acc[8] = v * n2;
+            }
         }
     }
 #ifdef QP_SWEEPSTATS
@@ -580,8 +604,9 @@ __device__ void grad_ctrl(const RowCtx& c) {
         w.cvec[it] = -g;
     }
 }
-// cvec = G'v in control space (yv accumulators)
-__device__ void gtv_ctrl(const RowCtx& c) {
+// cvec = G'v in control space: the yv accumulators of the BUILD sweep (predictor), or the two parts left by the AFF sweep
+// combined with sigma*mu (corrector: v = part0 - sigma_mu * part1)
+__device__ void gtv_ctrl(const RowCtx& c, bool corrector = false, double sigma_mu = 0.0) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int oq = d.oq;
@@ -591,12 +616,14 @@ __device__ void gtv_ctrl(const RowCtx& c) {
             w.cvec[it] = 0;
             continue;
         }
-        double g = w.cpacc[((size_t)a * oq + j6) * 12 + 6 + k];
+        const double* ac = w.cpacc + ((size_t)a * oq + j6) * 12;
+        double g = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
         for (int o = 0; o < d.nb; ++o) {
             if (o == a) continue;
             const int lo = a < o ? a : o, hi = a < o ? o : a;
             const int pr = lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1);
-            const double v = w.pracc[((size_t)pr * oq + j6) * 12 + 6 + k];
+            const double* ap = w.pracc + ((size_t)pr * oq + j6) * 12;
+            const double v = corrector ? ap[k] - sigma_mu * ap[3 + k] : ap[6 + k];
             g += (a == lo) ? v : -v;
         }
         w.cvec[it] = g;
@@ -1931,14 +1958,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         double sigma = mu_aff / mu;
         sigma = sigma * sigma * sigma;
         io.sigma_mu = sigma * mu;
-        // ---- corrector
+        // ---- corrector (its right-hand side was accumulated by the AFF sweep in two parts)
         __threadfence_block();
         __syncthreads();
-        SWEEP(PASS_CORR_RHS);
         PROF(8);
-        __threadfence_block();
-        __syncthreads();
-        gtv_ctrl(c);
+        gtv_ctrl(c, true, io.sigma_mu);
         __threadfence_block();
         __syncthreads();
         apply_FT(d, w, w.cvec, w.rhs, 1.0);
@@ -1978,7 +2002,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
             ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
         }
-        rows_swept += 5 * nrows_free;
+        rows_swept += 4 * nrows_free;
         __threadfence_block();
         __syncthreads();
         PROF(11);
