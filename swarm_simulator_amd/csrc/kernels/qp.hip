@@ -253,7 +253,8 @@ __device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
 // only checked once (presolve).  Work item = one free control point of one batch agent (all its bound and frozen
 // rows), then one (pair, control point).
 // ------------------------------------------------------------------------------------------------------------
-enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY };
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY,
+       PASS_UPBUILD /* UPDATE of iteration i fused with BUILD of iteration i+1: one read of the row state instead of two */ };
 
 struct PassIO {
     // inputs
@@ -308,8 +309,12 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         double s = slack < io.s_floor ? io.s_floor : slack;
         w.s[r] = s;
         w.z[r] = io.mu0 / s;
-    } else if (PASS == PASS_BUILD) {
-        const double s = w.s[r], z = w.z[r];
+    } else if (PASS == PASS_BUILD || PASS == PASS_UPBUILD) {
+        double s = w.s[r], z = w.z[r];
+        if (PASS == PASS_UPBUILD) {
+            s += io.alpha * w.ds[r], z += io.alpha * w.dz[r];
+            w.s[r] = s, w.z[r] = z;
+        }
         const double rg = s - slack;
         wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
         v = -wgt * (rg - s);  // predictor: rc / z = s
@@ -377,7 +382,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int oq = d.oq, N = d.N;
-    constexpr bool accum = (PASS == PASS_BUILD || PASS == PASS_CORR_RHS || PASS == PASS_AFF);
+    constexpr bool build = (PASS == PASS_BUILD || PASS == PASS_UPBUILD);
+    constexpr bool accum = (build || PASS == PASS_CORR_RHS || PASS == PASS_AFF);
     constexpr bool aff = (PASS == PASS_AFF);  // S[0..2] / S[3..5] then hold the two parts of the corrector rhs (see row_op)
     constexpr bool pinned_only = (PASS == PASS_PRESOLVE);
     // ---- control points of batch agents: bound + frozen rows
@@ -411,7 +417,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                               (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo, wgt);
                 if (accum) {
                     const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);  // diagonal slots of the packed 3x3
-                    if (PASS == PASS_BUILD) {
+                    if (build) {
                         S[dg] += wgt;
                         gz[k] += sg * w.z[r];
                     }
@@ -436,7 +442,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
             if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
             if (accum) {
-                if (PASS == PASS_BUILD) {
+                if (build) {
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
                     S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
                     const double z = w.z[r];
@@ -452,11 +458,11 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         }
         if (accum) {
             double* acc = w.cpacc + (size_t)it * 12;
-            if (PASS == PASS_BUILD || aff) {
+            if (build || aff) {
 #pragma unroll
                 for (int e = 0; e < 6; ++e) acc[e] = S[e];
             }
-            if (PASS == PASS_BUILD) {
+            if (build) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) acc[9 + e] = gz[e];
             }
@@ -506,7 +512,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
         if (accum) {
             double* acc = w.pracc + (size_t)it * 12;
-            if (PASS == PASS_BUILD) {
+            if (build) {
                 acc[0] = wgt * n0 * n0, acc[1] = wgt * n0 * n1, acc[2] = wgt * n0 * n2;
                 acc[3] = wgt * n1 * n1, acc[4] = wgt * n1 * n2, acc[5] = wgt * n2 * n2;
                 const double z = w.z[r];
@@ -1875,10 +1881,13 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     pw.ncand = (int*)(pw.Sg + PL_NC * PL_NC);
     for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
         it_count = iter;
-        // ---- sweep 1: weights, accumulators, residual norms
-        io.sum0 = 0, io.vmax = 0;
+        // ---- sweep 1: weights, accumulators, residual norms (from the second iteration on it is fused into the previous
+        // iteration's update sweep)
         PROF(0);
-        SWEEP(PASS_BUILD);
+        if (iter == 0) {
+            io.sum0 = 0, io.vmax = 0;
+            SWEEP(PASS_BUILD);
+        }
         PROF(1);
         const double gap = block_reduce(io.sum0, 0, red);
         const double pres = block_reduce(io.vmax, 1, red);
@@ -1997,12 +2006,15 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         }
         PROF(10);
         io.alpha = alpha;
-        SWEEP(PASS_UPDATE);
         for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
             const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
             ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
         }
-        rows_swept += 4 * nrows_free;
+        __threadfence_block();
+        __syncthreads();
+        io.sum0 = 0, io.vmax = 0;
+        SWEEP(PASS_UPBUILD);  // (s, z) += alpha (ds, dz), then the next iteration's weights and residuals at the new point
+        rows_swept += 3 * nrows_free;
         __threadfence_block();
         __syncthreads();
         PROF(11);
