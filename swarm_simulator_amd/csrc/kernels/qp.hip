@@ -314,6 +314,7 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         if (PASS == PASS_UPBUILD) {
             s += io.alpha * w.ds[r], z += io.alpha * w.dz[r];
             w.s[r] = s, w.z[r] = z;
+            io.vmin = fmin(io.vmin, s * z);  // wide-neighbourhood test of the step just applied
         }
         const double rg = s - slack;
         wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
@@ -1873,6 +1874,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
     bool ok = false;
     int it_count = 0, polished = 0, early_tries = 0;
+    double gap_next = 0, pres_next = 0;
     double flops = 0, rows_swept = 0;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
@@ -1889,8 +1891,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             SWEEP(PASS_BUILD);
         }
         PROF(1);
-        const double gap = block_reduce(io.sum0, 0, red);
-        const double pres = block_reduce(io.vmax, 1, red);
+        const double gap = iter == 0 ? block_reduce(io.sum0, 0, red) : gap_next;
+        const double pres = iter == 0 ? block_reduce(io.vmax, 1, red) : pres_next;
         __threadfence_block();
         __syncthreads();
         grad_ctrl(c);  // cvec = -(2Qx + G'z)
@@ -1994,29 +1996,33 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         double alpha = 0.99 / block_reduce(io.vmax, 1, red);
         __threadfence_block();
         __syncthreads();
-        // ---- wide neighbourhood: no product below 1e-3 * mu(alpha)
+        // ---- step, wide neighbourhood (no product below 1e-3 * mu(alpha)) and the next iteration's first sweep in ONE pass:
+        // the step is applied speculatively ((s, z) += alpha (ds, dz), x += alpha dx) while the same sweep evaluates the
+        // neighbourhood test and the new weights/residuals.  In the rare case the test fails the sweep is repeated with the
+        // difference to the shorter step (0.8 alpha), which also corrects the iterate.
+        double applied = 0;
         for (int bt = 0; bt < 40; ++bt) {
-            io.alpha = alpha, io.sum0 = 0, io.vmin = 1e300;
-            SWEEP(PASS_NBHD);
-            const double mu_new = block_reduce(io.sum0, 0, red) / nrows_free;
+            const double delta = alpha - applied;
+            for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
+                const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
+                ctrl[((size_t)(first + a) * 3) * d.oq + rest] += delta * w.dx[i];
+            }
+            __threadfence_block();
+            __syncthreads();
+            io.alpha = delta, io.sum0 = 0, io.vmax = 0, io.vmin = 1e300;
+            SWEEP(PASS_UPBUILD);
+            applied = alpha;
+            gap_next = block_reduce(io.sum0, 0, red);
+            pres_next = block_reduce(io.vmax, 1, red);
             const double pmin = block_reduce(io.vmin, 2, red);
             rows_swept += nrows_free;
-            if (pmin >= 1e-3 * mu_new) break;
+            __threadfence_block();
+            __syncthreads();
+            if (pmin >= 1e-3 * gap_next / nrows_free) break;
             alpha *= 0.8;
         }
+        rows_swept += 2 * nrows_free;
         PROF(10);
-        io.alpha = alpha;
-        for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
-            const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
-            ctrl[((size_t)(first + a) * 3) * d.oq + rest] += alpha * w.dx[i];
-        }
-        __threadfence_block();
-        __syncthreads();
-        io.sum0 = 0, io.vmax = 0;
-        SWEEP(PASS_UPBUILD);  // (s, z) += alpha (ds, dz), then the next iteration's weights and residuals at the new point
-        rows_swept += 3 * nrows_free;
-        __threadfence_block();
-        __syncthreads();
         PROF(11);
     }
     if (!ok) {
