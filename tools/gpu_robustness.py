@@ -16,6 +16,9 @@ for mf in sys.argv[1:]:
         except RuntimeError as e:
             continue
         worlds.append(w); plans.append(pr)
+    if not plans:
+        print(f"{mf}: ECBS found no initial trajectory on any map, skipped")
+        continue
     M = max(q.M for q in plans)
     pl2 = []
     for q in plans:
