@@ -611,29 +611,33 @@ __device__ void grad_ctrl(const RowCtx& c) {
         w.cvec[it] = -g;
     }
 }
-// cvec = G'v in control space: the yv accumulators of the BUILD sweep (predictor), or the two parts left by the AFF sweep
-// combined with sigma*mu (corrector: v = part0 - sigma_mu * part1)
-__device__ void gtv_ctrl(const RowCtx& c, bool corrector = false, double sigma_mu = 0.0) {
+// rhs = rbase + F'(G'v) in one pass: gtv_ctrl + apply_FT + the add fused (every control-space entry of G'v is used by
+// exactly one reduced-space entry, so nothing is computed twice and two barriers and the cvec round trip disappear)
+__device__ void rhs_from_acc(const RowCtx& c, bool corrector, double sigma_mu) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int oq = d.oq;
-    for (int it = threadIdx.x; it < d.nb * 3 * oq; it += QP_THREADS) {
-        const int a = it / (3 * oq), k = (it / oq) % 3, j6 = it % oq;
-        if (j6 < 3 || j6 >= oq - 3) {
-            w.cvec[it] = 0;
-            continue;
+    const int oq = d.oq, nu = 3 * d.nb;
+    for (int it = threadIdx.x; it < d.nj * nu; it += QP_THREADS) {
+        const int j = it / nu + 1, u = it % nu, a = u / 3, k = u % 3;
+        double g[6];  // G'v at control points 6(j-1)+3 .. 6j+2 of (agent a, dim k)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int j6 = 6 * (j - 1) + 3 + q;
+            const double* ac = w.cpacc + ((size_t)a * oq + j6) * 12;
+            double gv = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
+            for (int o = 0; o < d.nb; ++o) {
+                if (o == a) continue;
+                const int lo = a < o ? a : o, hi = a < o ? o : a;
+                const double* ap = w.pracc + ((size_t)(lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12;
+                const double v = corrector ? ap[k] - sigma_mu * ap[3 + k] : ap[6 + k];
+                gv += (a == lo) ? v : -v;
+            }
+            g[q] = gv;
         }
-        const double* ac = w.cpacc + ((size_t)a * oq + j6) * 12;
-        double g = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
-        for (int o = 0; o < d.nb; ++o) {
-            if (o == a) continue;
-            const int lo = a < o ? a : o, hi = a < o ? o : a;
-            const int pr = lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1);
-            const double* ap = w.pracc + ((size_t)pr * oq + j6) * 12;
-            const double v = corrector ? ap[k] - sigma_mu * ap[3 + k] : ap[6 + k];
-            g += (a == lo) ? v : -v;
-        }
-        w.cvec[it] = g;
+        const double* L = w.Lk + 9 * j;
+        const size_t o0 = (size_t)(j - 1) * d.nk + u * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) w.rhs[o0 + e] = w.rbase[o0 + e] + g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
     }
 }
 
@@ -1944,13 +1948,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
         PROF(4);
         // ---- predictor
-        gtv_ctrl(c);  // cvec = G'v (v from BUILD)
-        __threadfence_block();
-        __syncthreads();
-        apply_FT(d, w, w.cvec, w.rhs, 1.0);
-        __threadfence_block();
-        __syncthreads();
-        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
+        rhs_from_acc(c, false, 0.0);  // rhs = rbase + F'G'v (v from the build sweep)
         __threadfence_block();
         __syncthreads();
         PROF(5);
@@ -1973,13 +1971,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __threadfence_block();
         __syncthreads();
         PROF(8);
-        gtv_ctrl(c, true, io.sigma_mu);
-        __threadfence_block();
-        __syncthreads();
-        apply_FT(d, w, w.cvec, w.rhs, 1.0);
-        __threadfence_block();
-        __syncthreads();
-        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) w.rhs[i] += w.rbase[i];
+        rhs_from_acc(c, true, io.sigma_mu);
         __threadfence_block();
         __syncthreads();
         PROF(5);
