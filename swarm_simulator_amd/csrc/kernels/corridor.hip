@@ -27,25 +27,31 @@ namespace {
 
 struct AxisCache {
     double lo, hi;  // extent the cached keys belong to
+    double vnext;   // the accumulated sample coordinate at which the loop of axis_keys stopped (to continue when hi grows)
     int n;          // number of samples
 };
 
 // Computes the voxel indices of the samples along one axis of `box` (rbp_corridor.hpp:47-63 for that axis):
 //   v = lo; c = 0; while (v < hi + 1e-6) { coord = (c == 0 && lo > world_min + 1e-6) ? lo - 1e-6 : v + 1e-6; ... v += res }
 // and DynamicEDTOctomap::getDistance's key computation floor((1/res_map) * (double)(float)coord) - key_min.
-// All lanes run the same scalar loop and store identical values.
-__device__ __forceinline__ int axis_keys(int* keys, double lo, double hi, double step, double world_lo, double rf,
-                                         int key_min, int dim) {
-    int c = 0;
-    for (double v = lo; v < hi + SP_EPSILON_FLOAT && c < SFC_MAXS; v += step, ++c) {
+// All lanes run the same scalar loop and store identical values.  (c0, v0) continue an earlier run with the same lo: the
+// accumulated coordinates are exactly those a fresh run would produce.
+__device__ __forceinline__ int axis_keys(int* keys, int cap, double lo, double hi, double step, double world_lo, double rf,
+                                         int key_min, int dim, int c0, double v0, double* vnext) {
+    int c = c0;
+    double v = v0;
+    for (; v < hi + SP_EPSILON_FLOAT && c < cap; v += step, ++c) {
         double coord = v + SP_EPSILON_FLOAT;
         if (c == 0 && lo > world_lo + SP_EPSILON_FLOAT) coord = lo - SP_EPSILON_FLOAT;
         float cf = (float)coord;  // octomap::point3d is float32
         int k = (int)floor(rf * (double)cf) - key_min;
         keys[c] = (k >= 0 && k < dim) ? k : -1;
     }
+    *vnext = v;
     return c;
 }
+
+#define SFC_SLAB 8  // samples of the short axis of a slab test (one box_res step: two or three)
 
 struct SfcCtx {
     const unsigned* mask;  // LDS occupancy bitmask (bit = dist < margin - 1e-6) or nullptr
@@ -53,60 +59,168 @@ struct SfcCtx {
     int dim[3], key_min[3];
     double rf, world_min[3], world_max[3], res[3];
     double margin_cmp;  // margin - 1e-6
-    int* keys[3];       // LDS
-    AxisCache cache[3];
+    int* keys[3];       // LDS, full extent of the box along each axis
+    int* skeys[3];      // LDS, the short axis of the slab under test
+    AxisCache cache[3], slab[3];
     unsigned long long samples;
+#ifdef SFC_PROFILE
+    long long t_keys, t_samp;
+#endif
 };
 
 // rbp_corridor.hpp:44-78.  Returns true if any sample reads dist < margin - 1e-6 (or lies outside the grid: -1).
 __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
+    // Two key lists per axis: the full extent of the current box and the short axis of the slab under test.  expand_box
+    // alternates "slab along e, full along the others", so with one list per axis every test recomputed a full axis; now
+    // a full list is rebuilt only when its lower end moves, and extended by one sample when its upper end grows.
+#ifdef SFC_PROFILE
+    const long long pt0 = wall_clock64();
+#endif
     int n[3];
+    const int* kp[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        if (!(c.cache[a].lo == box[a] && c.cache[a].hi == box[a + 3])) {
-            c.cache[a].n = axis_keys(c.keys[a], box[a], box[a + 3], c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a]);
-            c.cache[a].lo = box[a];
-            c.cache[a].hi = box[a + 3];
+        const double lo = box[a], hi = box[a + 3];
+        AxisCache& f = c.cache[a];
+        AxisCache& sl = c.slab[a];
+        if (f.lo == lo && f.hi == hi) {
+            kp[a] = c.keys[a], n[a] = f.n;
+        } else if (sl.lo == lo && sl.hi == hi) {
+            kp[a] = c.skeys[a], n[a] = sl.n;
+        } else if (f.lo == lo && hi > f.hi && f.n > 0) {  // upper end grew: continue the accumulation where it stopped
+            f.n = axis_keys(c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, f.vnext, &f.vnext);
+            f.hi = hi;
+            kp[a] = c.keys[a], n[a] = f.n;
+        } else if (hi - lo < (SFC_SLAB - 3) * c.res[a]) {
+            sl.n = axis_keys(c.skeys[a], SFC_SLAB, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, lo, &sl.vnext);
+            sl.lo = lo, sl.hi = hi;
+            kp[a] = c.skeys[a], n[a] = sl.n;
+        } else {
+            f.n = axis_keys(c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, lo, &f.vnext);
+            f.lo = lo, f.hi = hi;
+            kp[a] = c.keys[a], n[a] = f.n;
         }
-        n[a] = c.cache[a].n;
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef SFC_PROFILE
+    const long long pt1 = wall_clock64();
+    c.t_keys += pt1 - pt0;
+    struct Tm { SfcCtx& c; long long t; __device__ ~Tm() { c.t_samp += wall_clock64() - t; } } tm_{c, pt1};
+#endif
     const long long total = (long long)n[0] * n[1] * n[2];
     if (total == 0) return false;
+    if (c.mask && c.dim[2] <= 32) {
+        // COLUMN TEST: z is the fastest dimension of the occupancy bitmask, so the n2 samples of one (x, y) column are
+        // nz consecutive bits.  One lane tests a whole column: window of the bitmask at the column's bit offset, ANDed with
+        // the set of z cells the box touches.  The columns are visited in the reference's (x outer, y inner) order, 64 per
+        // step, and on a hit the first occupied z sample of the first occupied column is located, so the boolean AND the
+        // number of getDistance calls the reference would have made (early exit at the first obstacle) are unchanged --
+        // with n2 times fewer steps.
+        const int n2 = n[2], n1 = n[1], nyz = c.dim[1] * c.dim[2], nzz = c.dim[2];
+        unsigned zmask = 0;
+        int zneg = -1;  // first z sample outside the grid (getDistance = -1 there): every column "hits" at that sample
+        for (int q = 0; q < n2; ++q) {
+            const int kz = kp[2][q];
+            if (kz < 0) {
+                if (zneg < 0) zneg = q;
+            } else {
+                zmask |= 1u << kz;
+            }
+        }
+        const long long ncol = (long long)n[0] * n1;
+        int c1 = lane % n1, c0 = lane / n1;
+        const int d1 = 64 % n1, d0 = 64 / n1;
+        for (long long base = 0; base < ncol; base += 64) {
+            bool hit = false;
+            int ix = 0, iy = 0;
+            unsigned o = 0;
+            if (base + lane < ncol) {
+                ix = kp[0][c0], iy = kp[1][c1];
+                if ((ix | iy) < 0) {
+                    hit = true;
+                } else {
+                    o = (unsigned)ix * nyz + (unsigned)iy * nzz;
+                    const unsigned long long w2 = ((unsigned long long)c.mask[(o >> 5) + 1] << 32) | c.mask[o >> 5];
+                    hit = (((unsigned)(w2 >> (o & 31))) & zmask) != 0 || zneg >= 0;
+                }
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                const int L = __ffsll((long long)m) - 1;
+                int zf = 0;
+                if (lane == L && (ix | iy) >= 0) {
+                    zf = n2 - 1;
+                    for (int q = 0; q < n2; ++q) {
+                        const int kz = kp[2][q];
+                        const bool h = kz < 0 || ((c.mask[(o + kz) >> 5] >> ((o + kz) & 31)) & 1u);
+                        if (h) {
+                            zf = q;
+                            break;
+                        }
+                    }
+                }
+                zf = __shfl(zf, L);
+                c.samples += (unsigned long long)((base + L) * n2 + zf + 1);  // the reference stops at the first hit
+                return true;
+            }
+            c1 += d1;
+            if (c1 >= n1) c1 -= n1, c0++;
+            c0 += d0;
+        }
+        c.samples += (unsigned long long)total;
+        return false;
+    }
     // mixed-radix decomposition of the lane id and of the stride 64 in (n0, n1, n2), z fastest
     int c2 = lane % n[2], t = lane / n[2];
     int c1 = t % n[1], c0 = t / n[1];
     const int d2 = 64 % n[2], t64 = 64 / n[2];
     const int d1 = t64 % n[1], d0 = t64 / n[1];
     const int ny = c.dim[1], nz = c.dim[2];
-    for (long long base = 0; base < total; base += 64) {
-        bool hit = false;
-        if (base + lane < total) {
-            int ix = c.keys[0][c0], iy = c.keys[1][c1], iz = c.keys[2][c2];
-            if ((ix | iy | iz) < 0) {
-                hit = true;  // getDistance returns -1 outside the map
-            } else {
-                const unsigned cell = ((unsigned)ix * ny + iy) * nz + iz;
-                if (c.mask) {
-                    hit = (c.mask[cell >> 5] >> (cell & 31)) & 1u;
+    // Four 64-sample steps per trip: the dependent LDS reads (key -> occupancy word) of the four steps overlap, the ballots
+    // are then examined in the reference's order, so the early exit and the sample count stay exactly the reference's.
+    constexpr int SU = 4;
+    for (long long base = 0; base < total; base += 64 * SU) {
+        int kx[SU], ky[SU], kz[SU];
+        bool live[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            live[u] = base + 64 * u + lane < total;
+            kx[u] = live[u] ? kp[0][c0] : 0, ky[u] = live[u] ? kp[1][c1] : 0, kz[u] = live[u] ? kp[2][c2] : 0;
+            c2 += d2;
+            if (c2 >= n[2]) c2 -= n[2], c1++;
+            c1 += d1;
+            if (c1 >= n[1]) c1 -= n[1], c0++;
+            c0 += d0;
+        }
+        bool hit[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            hit[u] = false;
+            if (live[u]) {
+                if ((kx[u] | ky[u] | kz[u]) < 0) {
+                    hit[u] = true;  // getDistance returns -1 outside the map
                 } else {
-                    float d = c.grid[cell];
-                    hit = (double)d < c.margin_cmp;
+                    const unsigned cell = ((unsigned)kx[u] * ny + ky[u]) * nz + kz[u];
+                    if (c.mask) {
+                        hit[u] = (c.mask[cell >> 5] >> (cell & 31)) & 1u;
+                    } else {
+                        float d = c.grid[cell];
+                        hit[u] = (double)d < c.margin_cmp;
+                    }
                 }
             }
         }
-        unsigned long long m = __ballot(hit);
-        if (m) {
-            c.samples += (unsigned long long)(__ffsll((long long)m));  // the reference stops at the first hit
-            return true;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const long long rem = total - (base + 64 * u);
+            if (rem <= 0) break;
+            const unsigned long long m = __ballot(hit[u]);
+            if (m) {
+                c.samples += (unsigned long long)(__ffsll((long long)m));  // the reference stops at the first hit
+                return true;
+            }
+            c.samples += (unsigned long long)(rem < 64 ? rem : 64);
         }
-        c2 += d2;
-        if (c2 >= n[2]) c2 -= n[2], c1++;
-        c1 += d1;
-        if (c1 >= n[1]) c1 -= n[1], c0++;
-        c0 += d0;
-        long long rem = total - base;
-        c.samples += (unsigned long long)(rem < 64 ? rem : 64);
     }
     return false;
 }
@@ -165,11 +279,15 @@ __device__ void expand_box(SfcCtx& c, double* box, int lane) {
 }
 
 __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
+#ifdef SFC_PROFILE
+    const long long t_start = wall_clock64();
+#endif
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
     const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
     const int M = s.M, P = M + 1, MB = s.max_boxes;
     __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
+    __shared__ int slab_all[SFC_WAVES][3][SFC_SLAB];
     __shared__ unsigned mask[SFC_MASK_WORDS];
     extern __shared__ int box_log_all[];  // [SFC_WAVES][MB][P]
     int* box_log = box_log_all + (size_t)wave * MB * P;
@@ -203,13 +321,19 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
         c.dim[a] = w.dim[a], c.key_min[a] = w.key_min[a];
         c.world_min[a] = s.p.world_min[a], c.world_max[a] = s.p.world_max[a];
         c.keys[a] = keys_all[wave][a];
-        c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0;
+        c.skeys[a] = slab_all[wave][a];
+        c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0, c.cache[a].vnext = 0;
+        c.slab[a] = c.cache[a];
     }
     c.res[0] = c.res[1] = s.p.box_xy_res, c.res[2] = s.p.box_z_res;
     const double radius = s.radius[(size_t)mission * s.N + qi];
     c.margin_cmp = radius - SP_EPSILON_FLOAT;
     c.mask = (mask_fits && radius == radius0) ? mask : nullptr;  // agents with another radius read the float grid
     c.samples = 0;
+#ifdef SFC_PROFILE
+    c.t_keys = c.t_samp = 0;
+    const long long t_after_mask = wall_clock64();
+#endif
 
     const float* traj = s.init_traj + ((size_t)mission * s.N + qi) * P * 3;
     const double* T = s.T + (size_t)mission * P;
@@ -292,6 +416,12 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
         if (box_max > 0) times[box_max - 1] = T[M];  // makespan :237
         s.sfc_count[(size_t)mission * s.N + qi] = nbox;
         atomicAdd(&s.counters[(size_t)mission * CT_N + CT_SFC_SAMPLES], c.samples);
+#ifdef SFC_PROFILE
+        atomicAdd(&s.scalars[(size_t)mission * SC_N + 20], (double)c.t_keys);
+        atomicAdd(&s.scalars[(size_t)mission * SC_N + 21], (double)c.t_samp);
+        atomicAdd(&s.scalars[(size_t)mission * SC_N + 22], (double)(wall_clock64() - t_after_mask));
+        atomicAdd(&s.scalars[(size_t)mission * SC_N + 23], (double)(t_after_mask - t_start));
+#endif
     }
 }
 
