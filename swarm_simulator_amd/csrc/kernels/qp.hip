@@ -36,10 +36,10 @@
 #define QP_RCP_NEWTON 2
 #endif
 #ifndef QP_EARLY_TRIES
-#define QP_EARLY_TRIES 1
+#define QP_EARLY_TRIES 2
 #endif
 #ifndef QP_EARLY_TOL
-#define QP_EARLY_TOL 1e-7
+#define QP_EARLY_TOL 1e-6
 #endif
 #ifndef QP_EARLY_POLISH
 #define QP_EARLY_POLISH 1  // try the active-set polish before the interior-point loop has fully converged
@@ -1924,8 +1924,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         PROF(2);
         // EARLY CROSSOVER: the polish returns the exact optimum (KKT-verified on every row) as soon as the interior-point
         // iterate identifies the active set, which happens several iterations before the 1e-10 termination test: try it
-        // once, when the residuals and mu fall below QP_EARLY_TOL (tuned on the 50-map sweep: 1e-7 is accepted ~85% of the
-        // time); a refused attempt leaves the iterate untouched and the loop goes on to the 1e-10 test and the final polish.
+        // when the residuals and mu fall below QP_EARLY_TOL = 1e-6 and once more at mu < 1e-8 (tuned on the 50-map sweep);
+        // a refused attempt leaves the iterate untouched and the loop goes on to the 1e-10 test and the final polish.
         if (QP_EARLY_POLISH && S.p.polish && early_tries < QP_EARLY_TRIES && pres < QP_EARLY_TOL && dres < QP_EARLY_TOL && mu < (early_tries == 0 ? QP_EARLY_TOL : 1e-2 * QP_EARLY_TOL)) {
             early_tries++;
             const int acc = polish_entry(c, pw, lds, red2, flag2);
