@@ -29,6 +29,12 @@
 #endif
 #define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
 #define QP_MAX_ITERS 80
+#ifndef QP_MU0
+#define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
+#endif
+#ifndef QP_SFLOOR
+#define QP_SFLOOR 1e-1
+#endif
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU (512 / QP_THREADS)  // 2 with 512 threads: all 256 VGPRs for the wave-register path
 #endif
@@ -1862,7 +1868,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     __syncthreads();
     if (tid == 0) c_lds = c;
     __syncthreads();
-    io.mu0 = 1e-1, io.s_floor = 1e-1, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
+    io.mu0 = QP_MU0, io.s_floor = QP_SFLOOR, io.dreg = 1e-9, io.sigma_mu = 0, io.alpha = 0;
     // presolve: constant rows (pinned control points) must hold within 1e-6 (CPLEX default feasibility tolerance)
     io.vmax = 0;
     row_pass<PASS_PRESOLVE>(c, io);
