@@ -229,3 +229,18 @@ def test_sweep_driver_serial_and_batched(capsys):
             same += 1
         assert ratio(a) >= 1.0 and ratio(b) >= 1.0
     assert same >= 1
+
+
+def test_both_kernel_builds_agree(monkeypatch):
+    """the QP kernel is built twice (256 VGPRs, one workgroup per CU / 128 VGPRs, two per CU; csrc/Makefile) and picked per
+    launch by the number of resident missions: both must land on the same certified optimum"""
+    c = Case("c2_16agents_map3")
+    out = {}
+    for variant in ("w2", "w4"):
+        monkeypatch.setenv("RBP_QP_VARIANT", variant)
+        pr = c.with_corridor()
+        pl = planner.RBPPlanner(c.mission, c.param)
+        assert pl.update(False, pr), pl.last_error
+        assert np.abs(pr.ctrl - c.g["ctrl"]).max() < CTRL_TOL
+        out[variant] = pr.ctrl.copy()
+    assert np.abs(out["w2"] - out["w4"]).max() < 1e-7
