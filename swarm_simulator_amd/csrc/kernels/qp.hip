@@ -29,6 +29,12 @@
 #endif
 #define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
 #define QP_MAX_ITERS 80
+#ifndef QP_POLISH_FIRST
+#define QP_POLISH_FIRST 1
+#endif
+#ifndef QP_WARM_TAU
+#define QP_WARM_TAU 1e-3  // polish-first (Gauss-Seidel passes >= 2): rows closer than this to their bound are candidates
+#endif
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
@@ -259,7 +265,7 @@ __device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
 // only checked once (presolve).  Work item = one free control point of one batch agent (all its bound and frozen
 // rows), then one (pair, control point).
 // ------------------------------------------------------------------------------------------------------------
-enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY,
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY, PASS_CAND_GEO,
        PASS_UPBUILD /* UPDATE of iteration i fused with BUILD of iteration i+1: one read of the row state instead of two */ };
 
 struct PassIO {
@@ -373,6 +379,13 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         wgt = (z > s || s < 1e-6) ? fmax(z / s, 1e-300) : 0.0;  // candidate for the active set; the value orders the warm start
         w.cc[r] = wgt;
         v = slack;
+    } else if (PASS == PASS_CAND_GEO) {
+        // candidates from the geometry alone (no interior-point iterate): rows within QP_WARM_TAU of their bound at the
+        // current point.  Used from the second Gauss-Seidel pass on, where the current point is the previous pass's
+        // optimum of this very batch and its active rows sit at slack ~ 0.
+        wgt = slack < QP_WARM_TAU ? (slack < 1e-8 ? 1e3 : 1.0) : 0.0;
+        w.cc[r] = wgt;
+        v = slack;
     } else if (PASS == PASS_VERIFY) {
         const double sn = slack - gdx;  // slack at x + dx
         w.ds[r] = sn;
@@ -419,7 +432,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
                 double wgt = 0, v = 0;
                 row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, wgt, v);
-                if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0)
+                if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0)
                     emit_cand(d, w, *c.pw, r, j6, a, -1, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack,
                               (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo, wgt);
                 if (accum) {
@@ -447,7 +460,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             const double slack = w.rhc[fr] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
             double wgt = 0, v = 0;
             row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
-            if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
+            if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
             if (accum) {
                 if (build) {
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
@@ -516,7 +529,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         }
         double wgt = 0, v = 0;
         row_op<PASS>(slack, ga, gd, r, w, io, wgt, v);
-        if ((PASS == PASS_CAND || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
+        if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
         if (accum) {
             double* acc = w.pracc + (size_t)it * 12;
             if (build) {
@@ -1717,7 +1730,7 @@ __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
 // one batch QP of one mission (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int batch, int nbmax,
-                                              int reset_cost, int lds_doubles) {
+                                              int reset_cost, int lds_doubles, int pass_index) {
     const int mission = blockIdx.x, tid = threadIdx.x;
     if (S.status[mission] != 0) return;
     const int N = S.N, M = S.M;
@@ -1877,10 +1890,6 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
         return;
     }
-    row_pass<PASS_INIT>(c, io);
-    __threadfence_block();
-    __syncthreads();
-
     const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
     bool ok = false;
     int it_count = 0, polished = 0, early_tries = 0;
@@ -1891,6 +1900,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     pw.V = w.polish + PL_NC * 14;
     pw.Sg = pw.V + (size_t)(PL_NC + 1) * d.nj * d.nk;
     pw.ncand = (int*)(pw.Sg + PL_NC * PL_NC);
+    row_pass<PASS_INIT>(c, io);
+    __threadfence_block();
+    __syncthreads();
     for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
         it_count = iter;
         // ---- sweep 1: weights, accumulators, residual norms (from the second iteration on it is fused into the previous
@@ -1932,9 +1944,17 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // iterate identifies the active set, which happens several iterations before the 1e-10 termination test: try it
         // when the residuals and mu fall below QP_EARLY_TOL = 1e-6 and once more at mu < 1e-8 (tuned on the 50-map sweep);
         // a refused attempt leaves the iterate untouched and the loop goes on to the 1e-10 test and the final polish.
-        if (QP_EARLY_POLISH && S.p.polish && early_tries < QP_EARLY_TRIES && pres < QP_EARLY_TOL && dres < QP_EARLY_TOL && mu < (early_tries == 0 ? QP_EARLY_TOL : 1e-2 * QP_EARLY_TOL)) {
-            early_tries++;
-            const int acc = polish_entry(c, pw, lds, red2, flag2);
+        // POLISH FIRST (Gauss-Seidel passes >= 2, e.g. plan/iteration = 50 of BASELINE config C5): the current point is the
+        // previous pass's optimum of this batch, only the frozen neighbours have moved a little, so the active set is
+        // mostly unchanged.  Before the first interior-point iteration the active-set step is tried directly with the rows
+        // near their bounds as candidates; it is accepted only under the same full KKT check as always (so it IS the
+        // optimum of this pass's QP), otherwise the interior-point method runs as in the first pass.
+        const bool polish_first = QP_POLISH_FIRST && pass_index > 0 && iter == 0;
+        const bool early = QP_EARLY_POLISH && early_tries < QP_EARLY_TRIES && pres < QP_EARLY_TOL && dres < QP_EARLY_TOL &&
+                           mu < (early_tries == 0 ? QP_EARLY_TOL : 1e-2 * QP_EARLY_TOL);
+        if (S.p.polish && (polish_first || early)) {
+            if (!polish_first) early_tries++;
+            const int acc = polish_entry(c, pw, lds, red2, flag2, polish_first);
             __syncthreads();
             PROF(0);
 #ifdef QP_POLSTATS
@@ -2029,7 +2049,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     // ---- active-set polish
     if (S.p.polish && !polished) {
-        const int acc = polish_entry(c, pw, lds, red2, flag2);
+        const int acc = polish_entry(c, pw, lds, red2, flag2, false);
         polished = acc == 0 ? 1 : 0;
         PROF(0);
         if (acc != 0 && tid == 0) scal[7] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
@@ -2067,7 +2087,7 @@ __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(D
                                                                int biter, int nbmax, int lds_doubles) {
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
-            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0), lds_doubles);
+            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0), lds_doubles, it);
             __threadfence_block();
             __syncthreads();
         }
