@@ -386,6 +386,8 @@ void rbp_session_destroy(rbp_session* s) {
 static int one_shot(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan, int stages,
                     int agent_begin = 0, int agent_end = -1) {
     if (!mission || !param || !plan) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    if (stages == RBP_STAGE_PLANNER && !(plan->sfc_count && plan->sfc_box && plan->sfc_time && plan->rsfc_normal && plan->rsfc_time))
+        return fail(RBP_ERR_BAD_ARGUMENT, "RBPPlanner::update needs the corridor (plan.sfc_* and plan.rsfc_*) as input");
     rbp_world dummy_world;
     float zero = 0.0f;
     if (!world) {  // planner stage does not read the map

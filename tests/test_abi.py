@@ -75,3 +75,14 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(root, f), errors="ignore").read()
                 for needle in ("oracle_lib", "rbp_oracle", "oracle/", "import oracle", "from oracle"):
                     assert needle not in text, (f, needle)
+
+
+def test_planner_call_without_corridor_is_refused():
+    """RBPPlanner::update reads SFC/RSFC (rbp_planner.hpp:435-511): a plan without them is a caller error, reported as
+    such before any device work (argument check only: runs without a GPU)."""
+    c = Case("c1_4agents_empty_joint")
+    pr = c.with_corridor()
+    pr.rsfc_normal = None
+    pl = planner.RBPPlanner(c.mission, c.param)
+    assert pl.update(False, pr) is False
+    assert pl.rc == A.RBP_ERR_BAD_ARGUMENT and "corridor" in pl.last_error
