@@ -601,33 +601,43 @@ __device__ void apply_F(const QpDims& d, const QpWs& w, const double* du, double
     }
 }
 
-// cvec = -(2Q x + G'z) in control space, for batch agents; returns via cvec.  gz comes from the BUILD accumulators.
-__device__ void grad_ctrl(const RowCtx& c) {
+// rbase = -F'(2Qx + G'z) in one pass (grad_ctrl + apply_FT fused, as in rhs_from_acc below); also returns this thread's
+// share of max|rbase| and max|2Qx + G'z| for the dual-residual test
+__device__ void rbase_from_acc(const RowCtx& c, double& dmax, double& gmax) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int oq = d.oq;
-    for (int it = threadIdx.x; it < d.nb * 3 * oq; it += QP_THREADS) {
-        const int a = it / (3 * oq), k = (it / oq) % 3, j6 = it % oq, m = j6 / 6, i = j6 % 6;
-        if (j6 < 3 || j6 >= oq - 3) {  // pinned control point: not a variable
-            w.cvec[it] = 0;
-            continue;
-        }
-        const double sc = w.segsc[m];
-        const double* xs = c.ctrl + ((size_t)(d.first + a) * 3 + k) * oq + 6 * m;
-        double g = 0;
+    const int oq = d.oq, nu = 3 * d.nb;
+    dmax = gmax = 0;
+    for (int it = threadIdx.x; it < d.nj * nu; it += QP_THREADS) {
+        const int j = it / nu + 1, u = it % nu, a = u / 3, k = u % 3;
+        const double* xb = c.ctrl + ((size_t)(d.first + a) * 3 + k) * oq;
+        double g[6];
 #pragma unroll
-        for (int jj = 0; jj < 6; ++jj) g += c_Qbase[6 * i + jj] * xs[jj];
-        g *= 2 * sc;
-        // G'z: own control-point accumulator + pair accumulators
-        g += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];
-        for (int o = 0; o < d.nb; ++o) {  // pairs (a,o): row = n.x_lo - n.x_hi
-            if (o == a) continue;
-            const int lo = a < o ? a : o, hi = a < o ? o : a;
-            const int pr = lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1);
-            const double v = w.pracc[((size_t)pr * oq + j6) * 12 + 9 + k];
-            g += (a == lo) ? v : -v;
+        for (int q = 0; q < 6; ++q) {
+            const int j6 = 6 * (j - 1) + 3 + q, m = j6 / 6, i = j6 % 6;
+            const double* xs = xb + 6 * m;
+            double gv = 0;
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) gv += c_Qbase[6 * i + jj] * xs[jj];
+            gv *= 2 * w.segsc[m];
+            gv += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];
+            for (int o = 0; o < d.nb; ++o) {  // pairs (a,o): row = n.x_lo - n.x_hi
+                if (o == a) continue;
+                const int lo = a < o ? a : o, hi = a < o ? o : a;
+                const double v = w.pracc[((size_t)(lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12 + 9 + k];
+                gv += (a == lo) ? v : -v;
+            }
+            g[q] = -gv;
+            gmax = fmax(gmax, fabs(gv));
         }
-        w.cvec[it] = -g;
+        const double* L = w.Lk + 9 * j;
+        const size_t o0 = (size_t)(j - 1) * d.nk + u * 3;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double r = g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
+            w.rbase[o0 + e] = r;
+            dmax = fmax(dmax, fabs(r));
+        }
     }
 }
 // rhs = rbase + F'(G'v) in one pass: gtv_ctrl + apply_FT + the add fused (every control-space entry of G'v is used by
@@ -1917,15 +1927,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const double pres = iter == 0 ? block_reduce(io.vmax, 1, red) : pres_next;
         __threadfence_block();
         __syncthreads();
-        grad_ctrl(c);  // cvec = -(2Qx + G'z)
-        __threadfence_block();
-        __syncthreads();
-        apply_FT(d, w, w.cvec, w.rbase, 1.0);  // rbase = -F'(2Qx + G'z)
-        __threadfence_block();
-        __syncthreads();
-        double dmax = 0, gmax = 0;
-        for (int i = tid; i < d.nj * d.nk; i += QP_THREADS) dmax = fmax(dmax, fabs(w.rbase[i]));
-        for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) gmax = fmax(gmax, fabs(w.cvec[i]));
+        double dmax, gmax;
+        rbase_from_acc(c, dmax, gmax);  // rbase = -F'(2Qx + G'z)
         const double dres = block_reduce(dmax, 1, red) / (1.0 + block_reduce(gmax, 1, red));
         const double mu = gap / nrows_free;
         rows_swept += nrows_free;
