@@ -1771,6 +1771,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     double* red2 = red;
     int* flag2 = flag;
 
+    PROF_DECL;
     mission_constants(d, T, const_cast<QpWs&>(w));
     init_block_pads(d, w);
 
@@ -1885,7 +1886,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     __threadfence_block();
     __syncthreads();
-    PROF_DECL;
+    PROF(8);  // batch setup: constants, SFC boxes, presolve lists, row constants
     PassIO io;
     __shared__ RowCtx c_lds;  // the sweeps' view of the row context (see sweep<>)
     __syncthreads();

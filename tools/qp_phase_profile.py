@@ -12,7 +12,7 @@ m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), NA, p)
 s = planner.Session(worlds, [m] * K, p, plans)
 s.run(); st = s.download()
 sc = s.scalars()
-names = ["polish (+tail)", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "CORR sweep", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
+names = ["polish (+tail)", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "batch setup", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
 tot = sc[:, 8:20].sum(1)
 print("status", st, "iters", sc[:, 2])
 for i, n in enumerate(names):
