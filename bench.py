@@ -95,9 +95,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--agents", type=int, default=64, help="mission_<N>agents_15.json (64 = headline, 16 = C2)")
-    ap.add_argument("--missions-per-gpu", type=int, default=1000,
-                    help="missions resident per step on each GPU: 1000 = twenty passes of the reference's 50-map sweep (one "
-                         "workgroup per mission, ~4 per CU, handed out by the dispatcher as CUs free up); 50 = exactly one sweep")
+    ap.add_argument("--missions-per-gpu", type=int, default=2000,
+                    help="missions resident per step on each GPU: 2000 = forty passes of the reference's 50-map sweep (one "
+                         "workgroup per mission, two resident per CU, the rest handed out by the dispatcher as slots free up: "
+                         "four rounds keep the tail short); 50 = exactly one sweep")
     ap.add_argument("--batch-size", type=int, default=4, help="plan/batch_size (4 = plan_rbp_test.launch; 8 = BASELINE config C5)")
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
