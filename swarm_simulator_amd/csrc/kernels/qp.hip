@@ -8,13 +8,18 @@
 // (u_j) and the three left of it are L_j u_j.  In these coordinates the batch QP has NO equality rows, every
 // inequality row (SFC bound :626-635, RSFC :638-684) touches exactly one knot, and the Newton matrix of a
 // primal-dual interior-point method, F'(2Q)F + J' W J, is block tridiagonal over the M-1 knots with dense
-// blocks of order nk = 9 * (batch agents).  One workgroup solves one mission's batch QP:
-//   * row sweeps (slack, weights, step lengths) stream the row state (s, z) from HBM/L2, coalesced along the
-//     control-point index;
+// blocks of order nk = 9 * (batch agents).  One workgroup runs one mission's whole batch schedule in one launch:
+//   * three row sweeps per interior-point iteration stream the row state (s, z, ds, dz) from HBM/L2, coalesced along
+//     the control-point index (affine sweep incl. both parts of the corrector rhs; step sweep; speculative
+//     step + neighbourhood test + next iteration's weights);
 //   * per-control-point 3x3 accumulators are expanded into the knot blocks (no atomics);
-//   * the block-tridiagonal Cholesky runs knot by knot with the three live nk x nk blocks in LDS.
+//   * the block-tridiagonal Cholesky: nk <= 36 twisted two-wave chains with one block row per lane in VGPRs and MFMA
+//     rank-k updates; wider batches an MFMA-tiled path (LDS-resident for nk <= 72);
+//   * an active-set polish (qp_polish.inc) turns the interior-point answer into the exact optimum, verified by a full
+//     KKT check; from the second Gauss-Seidel pass on it is tried before any interior-point iteration.
 // Batches of a mission are solved strictly in the reference's order (Gauss-Seidel, :140-148); parallelism comes
-// from the 3*nb coupled blocks inside a batch and from the K missions of a session.
+// from the 3*nb coupled blocks inside a batch and from the K missions of a session.  The file is compiled twice
+// (256 / 128 VGPRs, see the note above planner_workspace_bytes).
 #include <algorithm>
 #include <vector>
 
@@ -27,7 +32,7 @@
 #ifndef QP_THREADS
 #define QP_THREADS 512
 #endif
-#define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path on blocks in global memory
+#define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path (blocks in LDS up to nk = 72, else global)
 #define QP_MAX_ITERS 80
 #ifndef QP_POLISH_FIRST
 #define QP_POLISH_FIRST 1
