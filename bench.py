@@ -57,18 +57,8 @@ def build_inputs(map_ids, n_agents, param):
         w, pr = cache[mid]
         worlds.append(w)
         plans.append(pr.clone_inputs())
-    # a session needs one common M: pad shorter plans by repeating the goal waypoint (what ECBSPlanner does for agents
-    # that arrive early, ecbs_planner.hpp:63-68) up to the largest makespan of the batch
-    M = max(p.M for p in plans)
-    from swarm_simulator_amd.types import PlanResult
-    out = []
-    for p in plans:
-        if p.M < M:
-            pad = M - p.M
-            traj = np.concatenate([p.init_traj, np.repeat(p.init_traj[:, -1:, :], pad, axis=1)], axis=1)
-            T = np.concatenate([p.T, p.T[-1] + param.time_step * np.arange(1, pad + 1)])
-            p = PlanResult(traj, T)
-        out.append(p)
+    # every map keeps its own M = ECBS makespan + 2 (ecbs_planner.hpp:41-43): the session is ragged, nothing is padded
+    out = plans
     return m, worlds, out
 
 

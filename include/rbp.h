@@ -111,6 +111,14 @@ typedef struct rbp_plan {
     int32_t eq_size;        /* count_eq                    rbp_planner.hpp:59 */
     int32_t ineq_size;      /* count_lq                    rbp_planner.hpp:60 */
     int32_t qp_iterations;  /* total interior-point iterations spent (diagnostic, not in the reference) */
+    /* solver outcome (not in the reference, where cplex.solve() either returns an optimum or throws, rbp_planner.hpp:158-161):
+     * every batch QP ends with an active-set polish whose answer is accepted only under a full KKT check; a QP whose polish
+     * was refused keeps the interior-point answer (optimal to ~1e-5 m instead of ~1e-8 m) and is counted here */
+    int32_t qp_solves;      /* batch QPs solved (passes x batches) */
+    int32_t qp_unpolished;  /* of those, how many kept the interior-point answer; 0 = every answer is a certified optimum */
+    double kkt_max;         /* max over the batch QPs of the accepted answer's KKT residual: polished QPs max(row violation [m],
+                               -min multiplier / max(1, max multiplier)); unpolished QPs max(primal residual [m], relative dual
+                               residual, complementarity mu) */
 } rbp_plan;
 
 /* ---- the two stage calls (synchronous; results on return) -------------------------------------
@@ -140,7 +148,8 @@ typedef struct rbp_session rbp_session;
 
 enum { RBP_STAGE_CORRIDOR = 1, RBP_STAGE_PLANNER = 2, RBP_STAGE_ALL = 3 };
 
-/* worlds/missions/plans: arrays of K structs (host side); all plans must share N and M. */
+/* worlds/missions/plans: arrays of K structs (host side).  All plans share N; every mission keeps its own M (= ECBS makespan
+ * + 2, ecbs_planner.hpp:41-43) and max_boxes, exactly as the reference's map sweep plans each map with its own M. */
 int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
                        const rbp_param* param, const rbp_plan* plans);
 int rbp_session_run(rbp_session* s, int stages, void* stream);
@@ -150,7 +159,10 @@ int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t age
 /* blocks on `stream`, copies outputs into plans[0..K-1]; returns the first non-zero per-mission status
  * and, if `status` != NULL, every mission's status in status[0..K-1]. */
 int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream);
-/* restore T / corridor state to what was uploaded, so that `run` can be repeated (bench loops) */
+/* clears the per-run status / diagnostics so that `run` can be repeated (bench loops).  T, the SFC end times and the RSFC
+ * times are never rescaled on the device -- rbp_session_download applies time_scale to the host copies (rbp_planner.hpp:
+ * 250-264) -- so nothing else has to be restored; corridor inputs handed to rbp_session_create are uploaded again in case
+ * a CORRIDOR stage overwrote them. */
 int rbp_session_reset(rbp_session* s, void* stream);
 void rbp_session_destroy(rbp_session* s);
 
@@ -162,11 +174,32 @@ typedef struct rbp_counters {
     double qp_solves;       /* number of batch QPs solved */
     double qp_constraint_rows; /* inequality rows swept (rows x passes) */
     double qp_polished;     /* batch QPs whose active-set polish was accepted (the rest keep the interior-point answer) */
+    double qp_row_bytes;    /* algorithmic HBM bytes the QP kernel moves (row state and constants per sweep, knot blocks per
+                               factorisation / substitution): the numerator of the HBM-side roofline, DESIGN.md 3.3 */
+    double kkt_max;         /* max of rbp_plan::kkt_max over the missions */
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 
 /* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 24 (layout: kernels/rbp_dev.h SC_*) */
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
+
+/* ---- contexts: device memory kept across calls -------------------------------------------------
+ * "device selection passed through an opaque context handle created once".  A context owns one device
+ * arena that the synchronous calls below (and sessions created in it) reuse, so a caller that plans repeatedly -- the
+ * reference's ROS node, one Corridor::update + RBPPlanner::update per plan -- pays hipMalloc/hipFree once, not per call.
+ * rbp_corridor_update / rbp_planner_update (no context argument) use a per-thread default context on the calling thread's
+ * current device.  device < 0 = the calling thread's current device.  One live session per context at a time. */
+typedef struct rbp_ctx rbp_ctx;
+int rbp_ctx_create(rbp_ctx** out, int device);
+void rbp_ctx_destroy(rbp_ctx* ctx);
+int rbp_ctx_corridor_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
+int rbp_ctx_planner_update(rbp_ctx* ctx, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
+/* Corridor::update && RBPPlanner::update in one call (one upload, one download): what swarm_traj_planner_rbp.cpp:96-116 does
+ * back to back.  Returns the first failing stage's code. */
+int rbp_ctx_plan_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
+/* a batched session whose device memory is the context's arena (released back to it by rbp_session_destroy) */
+int rbp_session_create_in(rbp_ctx* ctx, rbp_session** out, int K, const rbp_world* worlds, const rbp_mission* missions,
+                          const rbp_param* param, const rbp_plan* plans);
 
 /* library/version/diagnostics */
 const char* rbp_version(void);

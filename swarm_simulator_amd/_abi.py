@@ -58,12 +58,14 @@ class rbp_plan(C.Structure):
                 ("rsfc_normal", c_float_p), ("rsfc_time", c_double_p),
                 ("coef", c_double_p), ("ctrl", c_double_p),
                 ("time_scale", C.c_double), ("total_cost", C.c_double),
-                ("x_size", C.c_int32), ("eq_size", C.c_int32), ("ineq_size", C.c_int32), ("qp_iterations", C.c_int32)]
+                ("x_size", C.c_int32), ("eq_size", C.c_int32), ("ineq_size", C.c_int32), ("qp_iterations", C.c_int32),
+                ("qp_solves", C.c_int32), ("qp_unpolished", C.c_int32), ("kkt_max", C.c_double)]
 
 
 class rbp_counters(C.Structure):
     _fields_ = [("sfc_samples", C.c_double), ("qp_flops", C.c_double), ("qp_ipm_iters", C.c_double),
-                ("qp_solves", C.c_double), ("qp_constraint_rows", C.c_double), ("qp_polished", C.c_double)]
+                ("qp_solves", C.c_double), ("qp_constraint_rows", C.c_double), ("qp_polished", C.c_double),
+                ("qp_row_bytes", C.c_double), ("kkt_max", C.c_double)]
 
 
 class rbp_mission_buf(C.Structure):

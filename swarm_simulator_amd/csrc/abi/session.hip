@@ -42,7 +42,23 @@ struct Arena {
     }
 };
 
+// host [N][mbk][w] <-> device slot [N][MB][w]
+template <class T>
+void repack_boxes(T* dst, int dst_mb, const T* src, int src_mb, int N, int w) {
+    const int nb = std::min(dst_mb, src_mb);
+    for (int a = 0; a < N; ++a) memcpy(dst + (size_t)a * dst_mb * w, src + (size_t)a * src_mb * w, sizeof(T) * (size_t)nb * w);
+}
+
 }  // namespace
+
+// A context owns one device arena that successive sessions (and the synchronous one-shot calls) reuse: the drop-in calls
+// rbp_corridor_update / rbp_planner_update would otherwise hipMalloc + hipFree ~10 MB per plan.
+struct rbp_ctx {
+    int device = 0;
+    char* base = nullptr;
+    size_t cap = 0;
+    bool busy = false;  // a live session is using the arena
+};
 
 struct rbp_session {
     int device = 0;
@@ -50,11 +66,12 @@ struct rbp_session {
     DevSession d{};
     rbp_param param{};
     Arena arena;
+    rbp_ctx* ctx = nullptr;  // non-null: the arena belongs to this context
     void* qp_ws = nullptr;
     size_t qp_ws_per_mission = 0;
-    std::vector<double> T0;           // uploaded T, for reset
+    std::vector<int> Mk, MBk;         // per-mission segments / box capacity (host copy of DevSession::Mk, MBk)
     std::vector<DevWorld> worlds_h;
-    // planner-stage inputs as uploaded (so that a planner-only run can be reset, too)
+    // planner-stage inputs as uploaded, in device layout (so that a run which overwrote them can be reset)
     std::vector<int> sfc_count0;
     std::vector<double> sfc_box0, sfc_time0, rsfc_time0;
     std::vector<float> rsfc_normal0;
@@ -86,8 +103,19 @@ void rbp_param_defaults(rbp_param* p) {  // param.hpp:44-70
 
 static size_t al(size_t n) { return ((n + 255) & ~size_t(255)) + 256; }
 
-int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
-                       const rbp_param* param, const rbp_plan* plans) {
+// effective batch size and number of batches solved per pass (setBatch, rbp_planner.hpp:849-872; the loop of :142)
+static void batch_schedule(const rbp_param& p, int N, int* bs_out, int* biter_out) {
+    int bs = p.sequential ? p.batch_size : N;
+    if (bs <= 0) bs = 1;
+    if (bs > N) bs = N;
+    const int bmax = (N + bs - 1) / bs;
+    int biter = p.sequential ? p.batch_iter : 1;
+    if (p.sequential && (biter < 0 || biter > bmax)) biter = bmax;
+    *bs_out = bs, *biter_out = biter;
+}
+
+static int session_create_impl(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
+                               const rbp_param* param, const rbp_plan* plans, rbp_ctx* ctx) {
     if (!out || K <= 0 || !worlds || !missions || !param || !plans) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
     *out = nullptr;
     int ndev = 0;
@@ -95,23 +123,43 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
         return fail(RBP_ERR_NO_DEVICE, "no HIP device: the RBP path has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(RBP_ERR_NO_DEVICE, "device index out of range");
     HIP_TRY(hipSetDevice(device));
-    const int N = plans[0].N, M = plans[0].M, MB = plans[0].max_boxes;
-    if (N <= 0 || M < 2 || MB <= 0) return fail(RBP_ERR_BAD_ARGUMENT, "need N >= 1, M >= 2, max_boxes >= 1");
+    // every mission keeps its own M = makespan + 2 (ecbs_planner.hpp:41-43) and box capacity; only N is common
+    const int N = plans[0].N;
+    int M = 0, MB = 0;  // session maxima = slot strides
     for (int k = 0; k < K; ++k) {
-        if (plans[k].N != N || plans[k].M != M || plans[k].max_boxes != MB || missions[k].N != N)
-            return fail(RBP_ERR_BAD_ARGUMENT, "all missions of a session must share N, M and max_boxes");
+        if (plans[k].N != N || missions[k].N != N) return fail(RBP_ERR_BAD_ARGUMENT, "all missions of a session must share N");
+        if (plans[k].N <= 0 || plans[k].M < 2 || plans[k].max_boxes <= 0)
+            return fail(RBP_ERR_BAD_ARGUMENT, "need N >= 1, M >= 2, max_boxes >= 1");
         if (!plans[k].T || !plans[k].init_traj || !worlds[k].dist)
             return fail(RBP_ERR_BAD_ARGUMENT, "plan.T / plan.init_traj / world.dist must be set");
+        M = std::max(M, (int)plans[k].M), MB = std::max(MB, (int)plans[k].max_boxes);
     }
     if (param->n != 5 || param->phi != 3) return fail(RBP_ERR_UNSUPPORTED_DEGREE, "RBPPlanner: n should be 5, phi 3");
-    auto* s = new rbp_session();
+    // the SFC kernel caches at most SFC_MAXS sample keys per axis (isObstacleInBox walks the box on the box_res lattice,
+    // rbp_corridor.hpp:47-63): reject worlds / resolutions that would be truncated instead of growing boxes through obstacles
+    if (!(param->box_xy_res > 0) || !(param->box_z_res > 0)) return fail(RBP_ERR_BAD_ARGUMENT, "box/xy_res and box/z_res must be positive");
+    for (int a = 0; a < 3; ++a) {
+        const double res = a < 2 ? param->box_xy_res : param->box_z_res;
+        const double ext = param->world_max[a] - param->world_min[a];
+        if (!(ext >= 0) || std::ceil(ext / res) + 3 > SFC_MAXS)
+            return fail(RBP_ERR_BAD_ARGUMENT, "world extent / box resolution exceeds the SFC sample cache (" + std::to_string(SFC_MAXS - 3) + " steps per axis)");
+    }
+    int bs = 1, biter = 0;
+    batch_schedule(*param, N, &bs, &biter);
+    if (biter > 0 && bs > planner_max_batch()) return fail(RBP_ERR_BAD_ARGUMENT, "batch wider than " + std::to_string(planner_max_batch()) + " agents (joint QP of a large mission) is not supported by the QP kernel");
+
+    struct Guard {  // every error path below releases the session (and with it the arena)
+        rbp_session* s;
+        ~Guard() {
+            if (s) rbp_session_destroy(s);
+        }
+    } guard{new rbp_session()};
+    rbp_session* s = guard.s;
     s->device = device;
     s->param = *param;
+    s->Mk.resize(K), s->MBk.resize(K);
+    for (int k = 0; k < K; ++k) s->Mk[k] = plans[k].M, s->MBk[k] = plans[k].max_boxes;
     const int P = M + 1, npair = N * (N - 1) / 2, oq = 6 * M;
-    // effective batch size (setBatch, rbp_planner.hpp:849-872)
-    int bs = param->sequential ? param->batch_size : N;
-    if (bs <= 0) bs = 1;
-    if (bs > N) bs = N;
     s->qp_ws_per_mission = std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs));
     {
         hipDeviceProp_t prop;
@@ -135,23 +183,35 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     size_t grid_bytes = 0;
     for (int k = 0; k < K; ++k)
         if (grid_of[k] == k) grid_bytes += al(sizeof(float) * (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2]);
-    size_t total = grid_bytes + al(sizeof(DevWorld) * K) + al(sizeof(float) * (size_t)K * N * P * 3) + al(sizeof(double) * K * P) +
-                   2 * al(sizeof(double) * (size_t)K * N * 9) + al(sizeof(double) * K * N) +
-                   2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) +
-                   al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
-                   al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
-                   2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
-                   al(sizeof(unsigned long long) * K * CT_N) + al(s->qp_ws_per_mission * K) + 4096;
-    hipError_t e = hipMalloc((void**)&s->arena.base, total);
-    if (e != hipSuccess) {
-        delete s;
-        return fail(RBP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    const size_t total = grid_bytes + al(sizeof(DevWorld) * K) + 2 * al(sizeof(int) * K) + al(sizeof(float) * (size_t)K * N * P * 3) +
+                         al(sizeof(double) * K * P) + 2 * al(sizeof(double) * (size_t)K * N * 9) + al(sizeof(double) * K * N) +
+                         2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) +
+                         al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
+                         al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
+                         2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
+                         al(sizeof(unsigned long long) * K * CT_N) + al(s->qp_ws_per_mission * K) + 4096;
+    if (ctx) {
+        if (ctx->busy) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: the context's arena is in use by another session");
+        if (ctx->device != device) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: context belongs to another device");
+        if (ctx->cap < total) {  // grow (with headroom, so that a sequence of slightly different plans does not reallocate)
+            if (ctx->base) (void)hipFree(ctx->base);
+            ctx->base = nullptr, ctx->cap = 0;
+            const size_t want = total + total / 4;
+            hipError_t e = hipMalloc((void**)&ctx->base, want);
+            if (e != hipSuccess) return fail(RBP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+            ctx->cap = want;
+        }
+        s->ctx = ctx, ctx->busy = true;
+        s->arena.base = ctx->base;
+    } else {
+        hipError_t e = hipMalloc((void**)&s->arena.base, total);
+        if (e != hipSuccess) return fail(RBP_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
     s->arena.size = total;
-    if (hipMemset(s->arena.base, 0, total) != hipSuccess) {
-        rbp_session_destroy(s);
-        return fail(RBP_ERR_HIP, "hipMemset failed");
-    }
+    // synchronous on purpose: small pageable host-to-device copies may be carried out by the CPU ahead of work queued on the
+    // stream, so an asynchronous clear could wipe what the uploads below have just written
+    HIP_TRY(hipMemset(s->arena.base, 0, total));
+    HIP_TRY(hipDeviceSynchronize());
     DevSession& d = s->d;
     d.K = K, d.N = N, d.M = M, d.max_boxes = MB, d.npair = npair;
     d.agent_begin = 0, d.agent_end = N;
@@ -181,6 +241,11 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     DevWorld* dw = A.take<DevWorld>(K);
     UP(dw, s->worlds_h.data(), sizeof(DevWorld) * K);
     d.worlds = dw;
+    int* dMk = A.take<int>(K);
+    int* dMBk = A.take<int>(K);
+    UP(dMk, s->Mk.data(), sizeof(int) * K);
+    UP(dMBk, s->MBk.data(), sizeof(int) * K);
+    d.Mk = dMk, d.MBk = dMBk;
     float* traj = A.take<float>((size_t)K * N * P * 3);
     double* T = A.take<double>((size_t)K * P);
     double* start = A.take<double>((size_t)K * N * 9);
@@ -199,11 +264,7 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     d.scalars = A.take<double>((size_t)K * SC_N);
     d.counters = A.take<unsigned long long>((size_t)K * CT_N);
     s->qp_ws = A.take<char>(s->qp_ws_per_mission * K);
-    if (A.off > A.size) {
-        rbp_session_destroy(s);
-        return fail(RBP_ERR_HIP, "arena overflow (internal sizing error)");
-    }
-    s->T0.resize((size_t)K * P);
+    if (A.off > A.size) return fail(RBP_ERR_HIP, "arena overflow (internal sizing error)");
     bool have_corr = true;
     for (int k = 0; k < K; ++k)
         have_corr = have_corr && plans[k].sfc_count && plans[k].sfc_box && plans[k].sfc_time && plans[k].rsfc_normal && plans[k].rsfc_time;
@@ -216,13 +277,13 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
     }
     s->have_corridor_inputs = have_corr;
     if (have_corr) {
-        s->sfc_count0.resize((size_t)K * N), s->sfc_box0.resize((size_t)K * N * MB * 6), s->sfc_time0.resize((size_t)K * N * MB);
-        s->rsfc_normal0.resize((size_t)K * npair * M * 3), s->rsfc_time0.resize((size_t)K * M);
+        s->sfc_count0.assign((size_t)K * N, 0), s->sfc_box0.assign((size_t)K * N * MB * 6, 0.0), s->sfc_time0.assign((size_t)K * N * MB, 0.0);
+        s->rsfc_normal0.assign((size_t)K * npair * M * 3, 0.0f), s->rsfc_time0.assign((size_t)K * M, 0.0);
     }
     for (int k = 0; k < K; ++k) {
-        UP(traj + (size_t)k * N * P * 3, plans[k].init_traj, sizeof(float) * (size_t)N * P * 3);
-        UP(T + (size_t)k * P, plans[k].T, sizeof(double) * P);
-        memcpy(&s->T0[(size_t)k * P], plans[k].T, sizeof(double) * P);
+        const int Mq = plans[k].M, Pq = Mq + 1, MBq = plans[k].max_boxes;
+        UP(traj + (size_t)k * N * P * 3, plans[k].init_traj, sizeof(float) * (size_t)N * Pq * 3);
+        UP(T + (size_t)k * P, plans[k].T, sizeof(double) * Pq);
         UP(start + (size_t)k * N * 9, missions[k].start, sizeof(double) * N * 9);
         UP(goal + (size_t)k * N * 9, missions[k].goal, sizeof(double) * N * 9);
         UP(radius + (size_t)k * N, missions[k].radius, sizeof(double) * N);
@@ -230,31 +291,43 @@ int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* wo
         UP(ma + (size_t)k * N * 3, missions[k].max_acc, sizeof(double) * N * 3);
         if (have_corr) {
             memcpy(&s->sfc_count0[(size_t)k * N], plans[k].sfc_count, sizeof(int) * N);
-            memcpy(&s->sfc_box0[(size_t)k * N * MB * 6], plans[k].sfc_box, sizeof(double) * (size_t)N * MB * 6);
-            memcpy(&s->sfc_time0[(size_t)k * N * MB], plans[k].sfc_time, sizeof(double) * (size_t)N * MB);
-            memcpy(&s->rsfc_normal0[(size_t)k * npair * M * 3], plans[k].rsfc_normal, sizeof(float) * (size_t)npair * M * 3);
-            memcpy(&s->rsfc_time0[(size_t)k * M], plans[k].rsfc_time, sizeof(double) * M);
+            repack_boxes(&s->sfc_box0[(size_t)k * N * MB * 6], MB, plans[k].sfc_box, MBq, N, 6);
+            repack_boxes(&s->sfc_time0[(size_t)k * N * MB], MB, plans[k].sfc_time, MBq, N, 1);
+            memcpy(&s->rsfc_normal0[(size_t)k * npair * M * 3], plans[k].rsfc_normal, sizeof(float) * (size_t)npair * Mq * 3);
+            memcpy(&s->rsfc_time0[(size_t)k * M], plans[k].rsfc_time, sizeof(double) * Mq);
         }
     }
     d.init_traj = traj, d.T = T, d.start = start, d.goal = goal, d.radius = radius, d.max_vel = mv, d.max_acc = ma;
 #undef UP
     int rc = rbp_session_reset(s, nullptr);
-    if (rc) {
-        rbp_session_destroy(s);
-        return rc;
-    }
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    guard.s = nullptr;
     *out = s;
     return RBP_OK;
 }
 
+int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
+                       const rbp_param* param, const rbp_plan* plans) {
+    return session_create_impl(out, device, K, worlds, missions, param, plans, nullptr);
+}
+
+int rbp_session_create_in(rbp_ctx* ctx, rbp_session** out, int K, const rbp_world* worlds, const rbp_mission* missions,
+                          const rbp_param* param, const rbp_plan* plans) {
+    if (!ctx) return fail(RBP_ERR_BAD_ARGUMENT, "null context");
+    return session_create_impl(out, ctx->device, K, worlds, missions, param, plans, ctx);
+}
+
+// T, the SFC end times and the RSFC times are never rescaled on the device (timescale_kernel only records the factor and
+// rescales the coefficients; rbp_session_download applies it to its host copies), so a session can be re-run as it is:
+// reset clears the per-run status / diagnostics and puts back corridor inputs the caller uploaded, in case a CORRIDOR
+// stage overwrote them.
 int rbp_session_reset(rbp_session* s, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     hipStream_t st = (hipStream_t)stream;
     const DevSession& d = s->d;
     const int K = d.K, N = d.N, M = d.M, MB = d.max_boxes;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipMemcpyAsync(d.T, s->T0.data(), sizeof(double) * s->T0.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d.status, 0, sizeof(int) * K, st));
     HIP_TRY(hipMemsetAsync(d.scalars, 0, sizeof(double) * K * SC_N, st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * K * CT_N, st));
@@ -303,38 +376,64 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<int> stat(K);
     std::vector<double> sc((size_t)K * SC_N);
+    std::vector<double> boxbuf, timebuf;
 #define DN(dst, src, bytes) HIP_TRY(hipMemcpy((dst), (const void*)(src), (bytes), hipMemcpyDeviceToHost))
     DN(stat.data(), d.status, sizeof(int) * K);
     DN(sc.data(), d.scalars, sizeof(double) * K * SC_N);
     int first = 0;
-    // setBatch bookkeeping for the size fields (rbp_planner.hpp:58-60): last batch solved
-    int bs = s->param.sequential ? s->param.batch_size : N;
-    if (bs <= 0) bs = 1;
-    if (bs > N) bs = N;
-    int bmax = (N + bs - 1) / bs;
-    int biter = s->param.sequential ? s->param.batch_iter : 1;
-    if (s->param.sequential && (biter < 0 || biter > bmax)) biter = bmax;
+    int bs = 1, biter = 0;
+    batch_schedule(s->param, N, &bs, &biter);
     for (int k = 0; k < K; ++k) {
         rbp_plan& p = plans[k];
-        if (p.N != N || p.M != M || p.max_boxes != MB) return fail(RBP_ERR_BAD_ARGUMENT, "plan shape differs from the session");
-        DN(p.T, d.T + (size_t)k * P, sizeof(double) * P);
-        if (p.sfc_count) DN(p.sfc_count, d.sfc_count + (size_t)k * N, sizeof(int) * N);
-        if (p.sfc_box) DN(p.sfc_box, d.sfc_box + (size_t)k * N * MB * 6, sizeof(double) * (size_t)N * MB * 6);
-        if (p.sfc_time) DN(p.sfc_time, d.sfc_time + (size_t)k * N * MB, sizeof(double) * (size_t)N * MB);
-        if (p.rsfc_normal) DN(p.rsfc_normal, d.rsfc_normal + (size_t)k * d.npair * M * 3, sizeof(float) * (size_t)d.npair * M * 3);
-        if (p.rsfc_time) DN(p.rsfc_time, d.rsfc_time + (size_t)k * M, sizeof(double) * M);
-        if (p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oq);
-        if (p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oq);
+        const int Mq = s->Mk[k], Pq = Mq + 1, oqq = 6 * Mq, MBq = s->MBk[k];
+        if (p.N != N || p.M != Mq || p.max_boxes != MBq) return fail(RBP_ERR_BAD_ARGUMENT, "plan shape differs from the session");
         const double* q = &sc[(size_t)k * SC_N];
-        p.time_scale = q[SC_TIME_SCALE] > 0 ? q[SC_TIME_SCALE] : 1.0;
+        // timeScale (rbp_planner.hpp:250-264) multiplies T, the SFC end times and the RSFC times by time_scale: done here, on
+        // the host copies (the same IEEE products), because the device arrays stay unscaled (see rbp_session_reset)
+        const double ts = q[SC_TIME_SCALE] > 0 ? q[SC_TIME_SCALE] : 1.0;
+        DN(p.T, d.T + (size_t)k * P, sizeof(double) * Pq);
+        if (ts != 1.0)
+            for (int m = 0; m < Pq; ++m) p.T[m] *= ts;
+        if (p.sfc_count) DN(p.sfc_count, d.sfc_count + (size_t)k * N, sizeof(int) * N);
+        if (p.sfc_box) {
+            if (MBq == MB) {
+                DN(p.sfc_box, d.sfc_box + (size_t)k * N * MB * 6, sizeof(double) * (size_t)N * MB * 6);
+            } else {
+                boxbuf.resize((size_t)N * MB * 6);
+                DN(boxbuf.data(), d.sfc_box + (size_t)k * N * MB * 6, sizeof(double) * (size_t)N * MB * 6);
+                repack_boxes(p.sfc_box, MBq, boxbuf.data(), MB, N, 6);
+            }
+        }
+        if (p.sfc_time) {
+            timebuf.resize((size_t)N * MB);
+            DN(timebuf.data(), d.sfc_time + (size_t)k * N * MB, sizeof(double) * (size_t)N * MB);
+            std::vector<int> cnt(N);
+            DN(cnt.data(), d.sfc_count + (size_t)k * N, sizeof(int) * N);
+            if (ts != 1.0)
+                for (int a = 0; a < N; ++a)
+                    for (int b = 0; b < cnt[a] && b < MB; ++b) timebuf[(size_t)a * MB + b] *= ts;
+            repack_boxes(p.sfc_time, MBq, timebuf.data(), MB, N, 1);
+        }
+        if (p.rsfc_normal) DN(p.rsfc_normal, d.rsfc_normal + (size_t)k * d.npair * M * 3, sizeof(float) * (size_t)d.npair * Mq * 3);
+        if (p.rsfc_time) {
+            DN(p.rsfc_time, d.rsfc_time + (size_t)k * M, sizeof(double) * Mq);
+            if (ts != 1.0)
+                for (int m = 0; m < Mq; ++m) p.rsfc_time[m] *= ts;
+        }
+        if (p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
+        if (p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
+        p.time_scale = ts;
         p.total_cost = q[SC_TOTAL_COST];
         p.qp_iterations = (int)q[SC_IPM_ITERS];
+        p.qp_solves = (int)q[SC_QP_SOLVED];
+        p.qp_unpolished = (int)(q[SC_QP_SOLVED] - q[SC_POLISHED]);
+        p.kkt_max = q[SC_KKT_MAX];
         if (biter > 0) {
             int last = biter - 1, nb = std::min(bs, N - last * bs);
-            p.x_size = 3 * nb * oq;
-            p.eq_size = 3 * nb * 3 * (M + 1);
+            p.x_size = 3 * nb * oqq;
+            p.eq_size = 3 * nb * 3 * (Mq + 1);
             int nf = N - nb;
-            p.ineq_size = 2 * p.x_size + (nb * (nb - 1) / 2 + nb * nf) * oq;
+            p.ineq_size = 2 * p.x_size + (nb * (nb - 1) / 2 + nb * nf) * oqq;
         }
         if (status) status[k] = stat[k];
         if (!first && stat[k]) first = stat[k];
@@ -361,6 +460,8 @@ int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
         out->qp_solves += sc[(size_t)k * SC_N + SC_QP_SOLVED];
         out->qp_constraint_rows += sc[(size_t)k * SC_N + SC_ROWS];
         out->qp_polished += sc[(size_t)k * SC_N + SC_POLISHED];
+        out->qp_row_bytes += sc[(size_t)k * SC_N + SC_ROW_BYTES];
+        out->kkt_max = std::max(out->kkt_max, sc[(size_t)k * SC_N + SC_KKT_MAX]);
     }
     return RBP_OK;
 }
@@ -377,18 +478,49 @@ int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream) {
 
 void rbp_session_destroy(rbp_session* s) {
     if (!s) return;
-    if (s->arena.base) {
+    if (s->ctx) {
+        s->ctx->busy = false;  // the arena stays with the context
+    } else if (s->arena.base) {
         (void)hipSetDevice(s->device);
         (void)hipFree(s->arena.base);
     }
     delete s;
 }
 
-static int one_shot(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan, int stages,
-                    int agent_begin = 0, int agent_end = -1) {
+// ---- contexts ---------------------------------------------------------------------------------------------------------
+int rbp_ctx_create(rbp_ctx** out, int device) {
+    if (!out) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(RBP_ERR_NO_DEVICE, "no HIP device: the RBP path has no CPU fallback");
+    if (device < 0) (void)hipGetDevice(&device);  // the calling thread's current device
+    if (device < 0 || device >= ndev) return fail(RBP_ERR_NO_DEVICE, "device index out of range");
+    auto* c = new rbp_ctx();
+    c->device = device;
+    *out = c;
+    return RBP_OK;
+}
+
+void rbp_ctx_destroy(rbp_ctx* c) {
+    if (!c) return;
+    if (c->base) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->base);
+    }
+    delete c;
+}
+
+static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan,
+                    int stages, int agent_begin = 0, int agent_end = -1) {
     if (!mission || !param || !plan) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
-    if (stages == RBP_STAGE_PLANNER && !(plan->sfc_count && plan->sfc_box && plan->sfc_time && plan->rsfc_normal && plan->rsfc_time))
-        return fail(RBP_ERR_BAD_ARGUMENT, "RBPPlanner::update needs the corridor (plan.sfc_* and plan.rsfc_*) as input");
+    if (stages == RBP_STAGE_PLANNER) {
+        if (!(plan->sfc_count && plan->sfc_box && plan->sfc_time && plan->rsfc_normal && plan->rsfc_time))
+            return fail(RBP_ERR_BAD_ARGUMENT, "RBPPlanner::update needs the corridor (plan.sfc_* and plan.rsfc_*) as input");
+        for (int a = 0; a < plan->N; ++a)
+            if (plan->sfc_count[a] <= 0 || plan->sfc_count[a] > plan->max_boxes)
+                return fail(RBP_ERR_BAD_ARGUMENT, "RBPPlanner::update: plan.sfc_count must be in [1, max_boxes] for every agent (run Corridor::update first)");
+    }
     rbp_world dummy_world;
     float zero = 0.0f;
     if (!world) {  // planner stage does not read the map
@@ -397,10 +529,27 @@ static int one_shot(const rbp_world* world, const rbp_mission* mission, const rb
         dummy_world.res = 1.0, dummy_world.dist = &zero;
         world = &dummy_world;
     }
+    // without an explicit context the calling thread's own one is used (created on first use on its current device), so the
+    // drop-in calls do not allocate device memory per plan either
+    thread_local struct Tls {
+        rbp_ctx* c = nullptr;
+        ~Tls() { /* process exit: the runtime releases device memory; hipFree here could run after the runtime is gone */ }
+    } tls;
+    if (!ctx) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (tls.c && tls.c->device != dev) {
+            rbp_ctx_destroy(tls.c);
+            tls.c = nullptr;
+        }
+        if (!tls.c) {
+            int rc = rbp_ctx_create(&tls.c, dev);
+            if (rc) return rc;
+        }
+        ctx = tls.c;
+    }
     rbp_session* s = nullptr;
-    int dev = 0;
-    (void)hipGetDevice(&dev);  // the calling thread's current device (one process per GPU sets it once)
-    int rc = rbp_session_create(&s, dev, 1, world, mission, param, plan);
+    int rc = session_create_impl(&s, ctx->device, 1, world, mission, param, plan, ctx);
     if (rc) return rc;
     if (agent_end >= 0) rc = rbp_session_set_agent_range(s, agent_begin, agent_end);
     if (!rc) rc = rbp_session_run(s, stages, nullptr);
@@ -414,18 +563,33 @@ static int one_shot(const rbp_world* world, const rbp_mission* mission, const rb
 
 int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
     if (!world) return fail(RBP_ERR_BAD_ARGUMENT, "null world");
-    return one_shot(world, mission, param, plan, RBP_STAGE_CORRIDOR);
+    return one_shot(nullptr, world, mission, param, plan, RBP_STAGE_CORRIDOR);
 }
 
 int rbp_corridor_update_range(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan,
                               int32_t agent_begin, int32_t agent_end) {
     if (!world) return fail(RBP_ERR_BAD_ARGUMENT, "null world");
     if (agent_end < 0) return fail(RBP_ERR_BAD_ARGUMENT, "agent range outside [0, N]");
-    return one_shot(world, mission, param, plan, RBP_STAGE_CORRIDOR, agent_begin, agent_end);
+    return one_shot(nullptr, world, mission, param, plan, RBP_STAGE_CORRIDOR, agent_begin, agent_end);
 }
 
 int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
-    return one_shot(nullptr, mission, param, plan, RBP_STAGE_PLANNER);
+    return one_shot(nullptr, nullptr, mission, param, plan, RBP_STAGE_PLANNER);
+}
+
+int rbp_ctx_corridor_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
+    if (!ctx || !world) return fail(RBP_ERR_BAD_ARGUMENT, "null context / world");
+    return one_shot(ctx, world, mission, param, plan, RBP_STAGE_CORRIDOR);
+}
+
+int rbp_ctx_planner_update(rbp_ctx* ctx, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
+    if (!ctx) return fail(RBP_ERR_BAD_ARGUMENT, "null context");
+    return one_shot(ctx, nullptr, mission, param, plan, RBP_STAGE_PLANNER);
+}
+
+int rbp_ctx_plan_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {
+    if (!ctx || !world) return fail(RBP_ERR_BAD_ARGUMENT, "null context / world");
+    return one_shot(ctx, world, mission, param, plan, RBP_STAGE_ALL);
 }
 
 }  // extern "C"

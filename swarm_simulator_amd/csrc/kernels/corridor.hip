@@ -19,7 +19,7 @@
 // (compiled with -ffp-contract=off; HIP's float division and the f64 sqrt are correctly rounded).
 #include "rbp_dev.h"
 
-#define SFC_MAXS 512        // max samples per axis (world extent / box resolution + 2)
+// SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
 #define SFC_WAVES 4         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
 #define SFC_MASK_WORDS 8192  // 262144 cells = 32 KB; larger grids fall back to reading the float grid
 
@@ -285,12 +285,12 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
     const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
-    const int M = s.M, P = M + 1, MB = s.max_boxes;
+    const int M = s.Mk[mission], P = M + 1, PS = s.M + 1, MB = s.max_boxes, MBcap = s.MBk[mission];  // PS, MB: slot strides
     __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
     __shared__ int slab_all[SFC_WAVES][3][SFC_SLAB];
     __shared__ unsigned mask[SFC_MASK_WORDS];
     extern __shared__ int box_log_all[];  // [SFC_WAVES][MB][P]
-    int* box_log = box_log_all + (size_t)wave * MB * P;
+    int* box_log = box_log_all + (size_t)wave * MB * PS;
     const DevWorld w = s.worlds[mission];
     // ---- occupancy bitmask of this mission's grid for the radius of the group's first agent, built once per workgroup
     // with coalesced reads + ballots.  The SFC test only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     const long long t_after_mask = wall_clock64();
 #endif
 
-    const float* traj = s.init_traj + ((size_t)mission * s.N + qi) * P * 3;
-    const double* T = s.T + (size_t)mission * P;
+    const float* traj = s.init_traj + (size_t)mission * s.N * PS * 3 + (size_t)qi * P * 3;
+    const double* T = s.T + (size_t)mission * PS;
     double* boxes = s.sfc_box + ((size_t)mission * s.N + qi) * MB * 6;
     double* times = s.sfc_time + ((size_t)mission * s.N + qi) * MB;
     int nbox = 0, err = 0;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
             break;
         }
         expand_box(c, box, lane);
-        if (nbox >= MB) {
+        if (nbox >= MBcap) {
             err = RBP_ERR_SFC_OVERFLOW;
             break;
         }
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
         }
         if (box_max > 0) times[box_max - 1] = T[M];  // makespan :237
         s.sfc_count[(size_t)mission * s.N + qi] = nbox;
+
         atomicAdd(&s.counters[(size_t)mission * CT_N + CT_SFC_SAMPLES], c.samples);
 #ifdef SFC_PROFILE
         atomicAdd(&s.scalars[(size_t)mission * SC_N + 20], (double)c.t_keys);
@@ -439,21 +440,23 @@ __device__ __forceinline__ void v_normalize(float* a) {
 }
 
 __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
-    const int M = s.M, P = M + 1, N = s.N;
-    const long long per_mission = (long long)s.npair * M;
+    const int MS = s.M, PS = MS + 1, N = s.N;  // slot strides
+    const long long per_mission = (long long)s.npair * MS;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= per_mission * s.K) return;
     const int mission = (int)(gid / per_mission);
+    const int M = s.Mk[mission], P = M + 1;
     const long long r = gid % per_mission;
-    const int pair = (int)(r / M), seg = (int)(r % M);
+    const int pair = (int)(r / MS), seg = (int)(r % MS);
+    if (seg >= M) return;
     // invert pair index -> (qi, qj), qi < qj, qi-major (rbp_corridor.hpp:342-344)
     int qi = 0, rem = pair;
     while (rem >= N - 1 - qi) rem -= N - 1 - qi, qi++;
     const int qj = qi + 1 + rem;
-    if (pair == 0) s.rsfc_time[(size_t)mission * M + seg] = s.T[(size_t)mission * P + seg + 1];  // :390 (every shard)
+    if (pair == 0) s.rsfc_time[(size_t)mission * MS + seg] = s.T[(size_t)mission * PS + seg + 1];  // :390 (every shard)
     if (qi < s.agent_begin || qi >= s.agent_end) return;  // pair rows of another shard
-    const float* ti = s.init_traj + ((size_t)mission * N + qi) * P * 3 + 3 * seg;
-    const float* tj = s.init_traj + ((size_t)mission * N + qj) * P * 3 + 3 * seg;
+    const float* ti = s.init_traj + (size_t)mission * N * PS * 3 + (size_t)qi * P * 3 + 3 * seg;
+    const float* tj = s.init_traj + (size_t)mission * N * PS * 3 + (size_t)qj * P * 3 + 3 * seg;
     const double dw = s.p.downwash;
     float a[3], b[3], c[3], n[3], m[3];
 #pragma unroll
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
     }
     v_normalize(m);
     m[2] = (float)((double)m[2] / dw);  // :384
-    float* out = s.rsfc_normal + (((size_t)mission * s.npair + pair) * M + seg) * 3;
+    float* out = s.rsfc_normal + (size_t)mission * s.npair * MS * 3 + ((size_t)pair * M + seg) * 3;
     out[0] = m[0], out[1] = m[1], out[2] = m[2];
     if (v_norm(m) == 0) atomicCAS(&s.status[mission], 0, (int)RBP_ERR_INIT_TRAJ_COLLIDE);  // :385-388
 }

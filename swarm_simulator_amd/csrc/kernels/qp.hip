@@ -32,7 +32,7 @@
 #ifndef QP_THREADS
 #define QP_THREADS 512
 #endif
-#define QP_MAX_NB 64         // nk <= 36: wave-register path; wider: MFMA-tiled path (blocks in LDS up to nk = 72, else global)
+// QP_MAX_NB (rbp_dev.h): nk <= 36: wave-register path; wider: MFMA-tiled path (blocks in LDS up to nk = 72, else global)
 #define QP_MAX_ITERS 80
 #ifndef QP_POLISH_FIRST
 #define QP_POLISH_FIRST 1
@@ -286,7 +286,8 @@ struct PassIO {
 
 struct RowCtx {
     const PolishWs* pw;
-    const DevSession* S;
+    double* scal;  // this mission's diagnostic scalars (DevSession::scalars + mission * SC_N).  NOT a pointer to the DevSession:
+                   // taking the kernel argument's address forces the whole struct into scratch memory
     int mission;
     int lds_avail;  // doubles of dynamic LDS behind the work-area pointer handed to the phases
     QpDims d;
@@ -554,7 +555,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
 #ifdef QP_SWEEPSTATS
     if (PASS == PASS_STEP) {
         __syncthreads();
-        if (threadIdx.x == 0) c.S->scalars[(size_t)c.mission * SC_N + 23] += (double)(wall_clock64() - sw_t0);
+        if (threadIdx.x == 0) c.scal[23] += (double)(wall_clock64() - sw_t0);
     }
 #endif
 }
@@ -1728,18 +1729,39 @@ __device__ __noinline__ void solve_entry(BlkArgs b, double* rhs, double* lds) {
 // in sequential mode and as the interior-point warm start in every mode.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
-    const int M = s.M, P = M + 1, oq = 6 * M;
-    const size_t total = (size_t)s.K * s.N * 3 * oq;
+    const int MS = s.M, PS = MS + 1, oqS = 6 * MS;  // slot strides (the session's largest M)
+    const size_t per_mission = (size_t)s.N * 3 * oqS, total = (size_t)s.K * per_mission;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-        const int j6 = (int)(it % oq), k = (int)((it / oq) % 3);
-        const size_t qa = it / ((size_t)3 * oq);  // mission*N + agent
+        const int mission = (int)(it / per_mission);
+        const int M = s.Mk[mission], P = M + 1, oq = 6 * M;
+        const size_t rest = it % per_mission;
+        const int j6 = (int)(rest % oqS), k = (int)((rest / oqS) % 3), qi = (int)(rest / ((size_t)3 * oqS));
+        if (j6 >= oq) continue;
         const int m = j6 / 6, j = j6 % 6;
         // idx runs with m (one waypoint pair per segment); the `idx >= size-1` branch is unreachable for M+1 waypoints
-        const float* tr = s.init_traj + qa * P * 3;
+        const float* tr = s.init_traj + (size_t)mission * s.N * PS * 3 + (size_t)qi * P * 3;
         const int a = (j < 3) ? 0 : 1;
-        s.ctrl[it] = (1 - a) * (double)tr[3 * m + k] + a * (double)tr[3 * (m + 1) + k];
+        s.ctrl[(size_t)mission * per_mission + ((size_t)qi * 3 + k) * oq + j6] = (1 - a) * (double)tr[3 * m + k] + a * (double)tr[3 * (m + 1) + k];
     }
 }
+
+#ifdef QP_TRACE
+// developer build: per-iteration checksums of the first batch QP of a mission, written into the mission's coef slot
+#define TRC(slot, expr)                                                         \
+    do {                                                                        \
+        if (batch == 0 && pass_index == 0 && iter < 60) {                       \
+            const double v_ = (expr);                                           \
+            if (tid == 0) trc[iter * 16 + (slot)] = v_;                         \
+        }                                                                       \
+    } while (0)
+__device__ double trc_sum(const double* p, size_t n, double* red) {
+    double a = 0;
+    for (size_t i = threadIdx.x; i < n; i += QP_THREADS) a += fabs(p[i]);
+    return block_reduce(a, 0, red);
+}
+#else
+#define TRC(slot, expr)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // one batch QP of one mission (all threads of the workgroup)
@@ -1748,21 +1770,23 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
                                               int reset_cost, int lds_doubles, int pass_index) {
     const int mission = blockIdx.x, tid = threadIdx.x;
     if (S.status[mission] != 0) return;
-    const int N = S.N, M = S.M;
+    // M of this mission: made wave-uniform explicitly (an SGPR like every other dimension; as a per-lane value it was spilled
+    // and reloaded under divergent control flow with some lanes reading garbage)
+    const int N = S.N, M = __builtin_amdgcn_readfirstlane(S.Mk[mission]), MS = S.M;  // MS: slot stride of the per-mission arrays
     const int first = batch * nbmax;
     const int nb = min(nbmax, N - first);
     if (nb <= 0) return;
     RowCtx c;
-    c.S = &S, c.mission = mission, c.lds_avail = lds_doubles - 32;
+    c.scal = S.scalars + (size_t)mission * SC_N, c.mission = mission, c.lds_avail = lds_doubles - 32;
     c.d = make_dims(N, M, first, nb);
     c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
-    double* ctrl = S.ctrl + (size_t)mission * N * 3 * c.d.oq;
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
     c.ctrl = ctrl;
-    c.normals = S.rsfc_normal + (size_t)mission * S.npair * M * 3;
+    c.normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
     c.radius = S.radius + (size_t)mission * N;
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const double* T = S.T + (size_t)mission * (M + 1);
+    const double* T = S.T + (size_t)mission * (MS + 1);
     double* scal = S.scalars + (size_t)mission * SC_N;
 
     // dynamic LDS: [0,32) reduction scratch + flags (always live), then a work area shared in turn by the block
@@ -1783,7 +1807,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     // SFC box of every (batch agent, segment): first box with end time >= T[m+1]  (rbp_planner.hpp:447-453)
     for (int a = tid; a < nb; a += QP_THREADS) {
         const int qa = first + a;
-        const int nbx = S.sfc_count[(size_t)mission * N + qa];
+        int nbx = S.sfc_count[(size_t)mission * N + qa];
+        if (nbx <= 0) {  // no SFC boxes: the planner stage was run on a plan whose corridor was never computed (caller error)
+            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_BAD_ARGUMENT);
+            nbx = 1;  // keeps the reads below inside the agent's slot; the mission is abandoned after the barrier
+        }
         const double* bt = S.sfc_time + ((size_t)mission * N + qa) * S.max_boxes;
         const double* bx = S.sfc_box + ((size_t)mission * N + qa) * S.max_boxes * 6;
         int bi = 0;
@@ -1807,8 +1835,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         double* xe = x + 6 * (M - 1);
         xe[5] = gl[k], xe[4] = xe[5] - hT * gl[k + 3] / 5, xe[3] = 2 * xe[4] - xe[5] + hT * hT * gl[k + 6] / 20;
     }
-    __threadfence_block();
+    __threadfence();
     __syncthreads();
+    if (__hip_atomic_load(&S.status[mission], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // set above: an agent without boxes
 
     // ---- presolve: a frozen-neighbour row  sg*n.(d_f - x_a) >= r_a + r_f  is implied by the SFC bounds of (a, segment) when
     // its slack is positive for EVERY x_a in the box; such rows cannot be active and are dropped (exact: the feasible
@@ -1903,13 +1932,18 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     row_pass<PASS_PRESOLVE>(c, io);
     const double pin_viol = block_reduce(io.vmax, 1, red);
     if (pin_viol > 1e-6) {
-        if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+        if (tid == 0) {
+            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+#ifndef QP_PROFILE
+            scal[SC_PROF0 + 1] = 1000.0 * batch + 1, scal[SC_PROF0 + 2] = pin_viol;  // why: a constant (pinned) row is violated
+#endif
+        }
         return;
     }
     const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
     bool ok = false;
-    int it_count = 0, polished = 0, early_tries = 0;
-    double gap_next = 0, pres_next = 0;
+    int it_count = 0, polished = 0, early_tries = 0, fail_reason = 3;
+    double gap_next = 0, pres_next = 0, kkt_ipm = 0;
     double flops = 0, rows_swept = 0;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
@@ -1919,6 +1953,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     row_pass<PASS_INIT>(c, io);
     __threadfence_block();
     __syncthreads();
+#ifdef QP_TRACE
+    double* trc = S.coef + (size_t)mission * N * 3 * 6 * MS;
+#endif
     for (int iter = 0; iter < QP_MAX_ITERS; ++iter) {
         it_count = iter;
         // ---- sweep 1: weights, accumulators, residual norms (from the second iteration on it is fused into the previous
@@ -1938,6 +1975,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const double dres = block_reduce(dmax, 1, red) / (1.0 + block_reduce(gmax, 1, red));
         const double mu = gap / nrows_free;
         rows_swept += nrows_free;
+        kkt_ipm = fmax(pres, fmax(dres, mu));
+        TRC(0, gap); TRC(1, pres); TRC(2, dres); TRC(3, trc_sum(w.rbase, (size_t)d.nj * d.nk, red)); TRC(4, trc_sum(w.cpacc, (size_t)12 * d.nb * d.oq, red));
         if (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) {
             ok = true;
             break;
@@ -1979,16 +2018,23 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         PROF(3);
         __threadfence_block();
         __syncthreads();
-        if (!factor_entry(ba, lA, flag)) break;
+        TRC(5, trc_sum(w.Td, (size_t)d.nj * d.ldb * d.ldb, red));
+        if (!factor_entry(ba, lA, flag)) {
+            fail_reason = 2;  // Newton matrix not positive definite
+            break;
+        }
         flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
         PROF(4);
+        TRC(6, trc_sum(d.nk <= 36 ? w.Lf : w.Td, d.nk <= 36 ? (size_t)d.nj * 2 * d.nk * d.nk : (size_t)d.nj * d.ldb * d.ldb, red));
         // ---- predictor
         rhs_from_acc(c, false, 0.0);  // rhs = rbase + F'G'v (v from the build sweep)
         __threadfence_block();
         __syncthreads();
         PROF(5);
+        TRC(7, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
         solve_entry(ba, w.rhs, lA);
         PROF(6);
+        TRC(8, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
         apply_F(d, w, w.rhs, w.dxa);
         __threadfence_block();
         __syncthreads();
@@ -1999,6 +2045,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const double a_aff = 1.0 / block_reduce(io.vmax, 1, red);
         const double q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red), q2 = block_reduce(io.sum2, 0, red);
         const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows_free;
+        TRC(9, a_aff); TRC(10, mu_aff);
         double sigma = mu_aff / mu;
         sigma = sigma * sigma * sigma;
         io.sigma_mu = sigma * mu;
@@ -2010,8 +2057,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __threadfence_block();
         __syncthreads();
         PROF(5);
+        TRC(11, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
         solve_entry(ba, w.rhs, lA);
         PROF(6);
+        TRC(12, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
         apply_F(d, w, w.rhs, w.dx);
         __threadfence_block();
         __syncthreads();
@@ -2021,6 +2070,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         SWEEP(PASS_STEP);
         PROF(9);
         double alpha = 0.99 / block_reduce(io.vmax, 1, red);
+        TRC(13, alpha);
         __threadfence_block();
         __syncthreads();
         // ---- step, wide neighbourhood (no product below 1e-3 * mu(alpha)) and the next iteration's first sweep in ONE pass:
@@ -2053,7 +2103,12 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         PROF(11);
     }
     if (!ok) {
-        if (tid == 0) atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+        if (tid == 0) {
+            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+#ifndef QP_PROFILE
+            scal[SC_PROF0 + 1] = 1000.0 * batch + fail_reason, scal[SC_PROF0 + 2] = it_count;  // why: 2 factor, 3 iteration cap
+#endif
+        }
         return;
     }
     // ---- active-set polish
@@ -2061,9 +2116,13 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const int acc = polish_entry(c, pw, lds, red2, flag2, false);
         polished = acc == 0 ? 1 : 0;
         PROF(0);
-        if (acc != 0 && tid == 0) scal[7] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
+#ifndef QP_PROFILE
+        if (acc != 0 && tid == 0) scal[SC_PROF0] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
+#endif
         __syncthreads();
     }
+    __syncthreads();
+    const double kkt = polished ? red[12] : kkt_ipm;
     // objective of this batch: sum x' Q_p x  (cplex.getObjValue, :164)
     double obj = 0;
     for (int it = tid; it < d.nb * 3 * M; it += QP_THREADS) {
@@ -2082,6 +2141,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         scal[SC_IPM_ITERS] += it_count;
         scal[SC_QP_SOLVED] += 1;
         scal[SC_POLISHED] += polished;
+        scal[SC_KKT_MAX] = fmax(scal[SC_KKT_MAX], kkt);
         scal[SC_FLOPS] += flops;
         scal[SC_ROWS] += rows_swept;
     }
@@ -2106,17 +2166,21 @@ __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(D
 // epilogue: Bernstein -> monomial (rbp_planner.hpp:170-196), timeScale (:209-266)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void coef_kernel(DevSession s) {
-    const int M = s.M, oq = 6 * M;
-    const size_t total = (size_t)s.K * s.N * 3 * M;
+    const int MS = s.M, oqS = 6 * MS;  // slot strides
+    const size_t per_mission = (size_t)s.N * 3 * MS, total = (size_t)s.K * per_mission;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(it % M);
-        const size_t u = it / M;  // (mission*N + agent)*3 + k
-        const int mission = (int)(u / ((size_t)s.N * 3));
+        const int mission = (int)(it / per_mission);
         if (s.status[mission] != 0) continue;
-        const double* T = s.T + (size_t)mission * (M + 1);
+        const int M = s.Mk[mission], oq = 6 * M;
+        const size_t rest = it % per_mission;
+        const int m = (int)(rest % MS);
+        const size_t u = rest / MS;  // agent*3 + k
+        if (m >= M) continue;
+        const double* T = s.T + (size_t)mission * (MS + 1);
         const double inv = 1.0 / (T[m + 1] - T[m]);
-        const double* v = s.ctrl + u * oq + 6 * m;
-        double* out = s.coef + u * oq + 6 * m;
+        const size_t base = (size_t)mission * s.N * 3 * oqS + u * oq + 6 * m;
+        const double* v = s.ctrl + base;
+        double* out = s.coef + base;
         for (int cidx = 0; cidx < 6; ++cidx) {
             const double tp = pow(inv, 5 - cidx);  // timeMatrix :695-700
             double acc = 0;
@@ -2176,11 +2240,11 @@ __device__ int real_roots(const double* cin, int deg, double* out) {
 
 // one workgroup per mission: max over (agent, dim, segment) of the per-segment scale, then rescale
 __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
-    const int mission = blockIdx.x, tid = threadIdx.x, M = s.M, N = s.N, oq = 6 * M, n = 5;
+    const int mission = blockIdx.x, tid = threadIdx.x, M = s.Mk[mission], MS = s.M, N = s.N, oq = 6 * M, n = 5;
     if (s.status[mission] != 0) return;
     __shared__ double red[8];
-    double* T = s.T + (size_t)mission * (M + 1);
-    double* coef = s.coef + (size_t)mission * N * 3 * oq;
+    const double* T = s.T + (size_t)mission * (MS + 1);
+    double* coef = s.coef + (size_t)mission * N * 3 * 6 * MS;
     double ts = 1;
     if (s.p.time_scale) {
         for (int it = tid; it < N * 3 * M; it += blockDim.x) {
@@ -2251,18 +2315,14 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
         __syncthreads();
     }
     if (tid == 0) s.scalars[(size_t)mission * SC_N + SC_TIME_SCALE] = ts;
-    if (ts != 1) {  // :236-265
+    // :236-265.  Only the coefficients are rescaled on the device: T, the SFC end times and the RSFC times stay as uploaded /
+    // as the corridor stage wrote them (so a session can be re-run without restoring anything) and rbp_session_download
+    // multiplies its host copies by time_scale -- the same IEEE product the reference computes in place (:250-264).
+    if (ts != 1) {
         for (int it = tid; it < N * 3 * oq; it += blockDim.x) {
             const int i = it % 6;
             coef[it] = pow(1.0 / ts, n - i) * coef[it];
         }
-        for (int it = tid; it < N * s.max_boxes; it += blockDim.x) {
-            const int qi = it / s.max_boxes, b = it % s.max_boxes;
-            if (b < s.sfc_count[(size_t)mission * N + qi]) s.sfc_time[((size_t)mission * N + qi) * s.max_boxes + b] *= ts;
-        }
-        for (int m = tid; m < M; m += blockDim.x) s.rsfc_time[(size_t)mission * M + m] *= ts;
-        __syncthreads();
-        for (int m = tid; m <= M; m += blockDim.x) T[m] *= ts;
     }
 }
 
@@ -2289,7 +2349,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
     const int bmax = (N + bs - 1) / bs;
     int biter = s.p.sequential ? s.p.batch_iter : 1;
     if (s.p.sequential && (biter < 0 || biter > bmax)) biter = bmax;
-    const size_t total = (size_t)s.K * N * 3 * 6 * M;
+    const size_t total = (size_t)s.K * N * 3 * 6 * M;  // M = s.M: the slot stride (largest M of the session)
     const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(dummy_kernel, dim3(g), dim3(256), 0, st, s);
     if (biter > 0) {
@@ -2319,6 +2379,9 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
                                ws_bytes_per_mission / sizeof(double), s.p.iteration, biter, bs, (int)(lds / sizeof(double)) - 2);
     }
     const size_t tot2 = (size_t)s.K * N * 3 * M;
+#ifdef QP_TRACE
+    return;  // the coef slot holds the trace
+#endif
     hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
     hipLaunchKernelGGL(timescale_kernel, dim3(s.K), dim3(256), 0, st, s);
 }

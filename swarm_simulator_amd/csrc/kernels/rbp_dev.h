@@ -1,4 +1,8 @@
-// rbp_dev.h — device-side layout of one session (K missions with common N, M) and kernel entry points.
+// rbp_dev.h — device-side layout of one session (K missions with common N, per-mission M) and kernel entry points.
+//
+// Every mission has its own segment count M_k = makespan + 2 (ecbs_planner.hpp:41-43, rbp_planner.hpp:35).  A mission's
+// slot in every array is sized for the session's largest M (DevSession::M, the STRIDE), but inside its slot the data is
+// laid out compactly with the mission's own M_k = Mk[mission] -- exactly the layout a one-mission session would have.
 //
 // HBM layout (all arrays mission-major, SoA inside a mission; sizes for the headline N=64, M=36):
 //   dist      [K] float grids, x-major / z-fastest (0.94 MB each)        — read by the SFC kernel
@@ -16,6 +20,9 @@
 
 #define SP_EPSILON 1e-9        /* reference: swarm_planner/include/sp_const.hpp:3 */
 #define SP_EPSILON_FLOAT 1e-6  /* sp_const.hpp:4 */
+#define QP_MAX_NB 64           /* widest batch (agents) one workgroup factorises: nk = 9 * 64 = 576 */
+inline int planner_max_batch() { return QP_MAX_NB; }
+#define SFC_MAXS 512           /* sfc_kernel: max samples per axis (world extent / box resolution + 3); checked at session create */
 
 struct DevWorld {
     int dim[3];
@@ -33,7 +40,9 @@ struct DevParam {
 
 // per-session pointers handed to kernels by value
 struct DevSession {
-    int K, N, M, max_boxes, npair;
+    int K, N, M, max_boxes, npair;  // M, max_boxes: session maxima = slot strides; per-mission values in Mk / MBk
+    const int* Mk;            // [K] segments of mission k (<= M)
+    const int* MBk;           // [K] box capacity of mission k (<= max_boxes): plan.max_boxes of the caller
     int agent_begin, agent_end;  // corridor stage only: agents (and pair rows i) of this shard, [0, N) when not sharded
     DevParam p;
     const DevWorld* worlds;   // [K]
@@ -56,7 +65,11 @@ struct DevSession {
     unsigned long long* counters;  // [K][4]: sfc samples, ...
 };
 
-enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6, SC_PROF0 = 8, SC_N = 24 };  // SC_PROF0..: per-phase cycle counters (QP_PROFILE builds)
+enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6,
+       SC_KKT_MAX = 7,    // max over the batch QPs of the KKT residual of the accepted answer (see rbp_plan::kkt_max)
+       SC_PROF0 = 8,      // SC_PROF0..SC_PROF0+15: per-phase cycle counters (QP_PROFILE builds); slot 8 otherwise: which batch was not polished
+       SC_ROW_BYTES = 24, // algorithmic HBM bytes of the QP kernel (row state, row constants, knot blocks)
+       SC_N = 28 };
 enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
 // launchers (defined in the .hip files)

@@ -59,6 +59,14 @@ def lib():
         L.rbp_session_scalars.argtypes = [C.c_void_p, A.c_double_p, C.c_int, C.c_void_p]
         L.rbp_session_destroy.argtypes = [C.c_void_p]
         L.rbp_session_destroy.restype = None
+        L.rbp_ctx_create.argtypes = [P(C.c_void_p), C.c_int]
+        L.rbp_ctx_destroy.argtypes = [C.c_void_p]
+        L.rbp_ctx_destroy.restype = None
+        L.rbp_ctx_corridor_update.argtypes = [C.c_void_p, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_ctx_planner_update.argtypes = [C.c_void_p, P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_ctx_plan_update.argtypes = [C.c_void_p, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param), P(A.rbp_plan)]
+        L.rbp_session_create_in.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param),
+                                            P(A.rbp_plan)]
         _lib = L
     return _lib
 
@@ -69,6 +77,8 @@ EXPORTED_SYMBOLS = [
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
     "rbp_version",
     "rbp_last_error", "rbp_device_count",
+    "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
+    "rbp_session_create_in",
 ]
 
 
@@ -76,17 +86,49 @@ def last_error():
     return lib().rbp_last_error().decode()
 
 
-class Corridor:
-    """rbp_corridor.hpp:11-26"""
+class Context:
+    """rbp_ctx: device memory kept across plans (include/rbp.h).  `device=None` = the calling thread's current device."""
 
-    def __init__(self, world: World, mission: Mission, param: Param):
-        self.world, self.mission, self.param = world, mission, param
+    def __init__(self, device=None):
+        self._h = C.c_void_p()
+        rc = lib().rbp_ctx_create(C.byref(self._h), -1 if device is None else int(device))
+        if rc:
+            raise RuntimeError(f"rbp_ctx_create failed rc={rc}: {ERROR_TEXT.get(rc, '')} | {last_error()}")
+
+    def plan_update(self, world: World, mission: Mission, param: Param, plan: PlanResult) -> int:
+        """Corridor::update && RBPPlanner::update in one call; returns the C ABI's code (0 = both true)."""
+        w, m, p, pl = world.c_struct(), mission.c_struct(), param.c_struct(), plan.c_struct()
+        rc = lib().rbp_ctx_plan_update(self._h, C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
+        plan.sync_from(pl)
+        return rc
+
+    def close(self):
+        if self._h:
+            lib().rbp_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Corridor:
+    """rbp_corridor.hpp:11-26.  `ctx`: optional Context whose device arena the call reuses (default: the library's
+    per-thread context)."""
+
+    def __init__(self, world: World, mission: Mission, param: Param, ctx: Context = None):
+        self.world, self.mission, self.param, self.ctx = world, mission, param, ctx
         self.last_error = ""
         self.rc = 0
 
     def update(self, log: bool, plan: PlanResult) -> bool:
         w, m, p, pl = self.world.c_struct(), self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
-        self.rc = lib().rbp_corridor_update(C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
+        if self.ctx is not None:
+            self.rc = lib().rbp_ctx_corridor_update(self.ctx._h, C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
+        else:
+            self.rc = lib().rbp_corridor_update(C.byref(w), C.byref(m), C.byref(p), C.byref(pl))
         self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
         return self.rc == 0
 
@@ -102,21 +144,25 @@ class Corridor:
 class RBPPlanner:
     """rbp_planner.hpp:19-84"""
 
-    def __init__(self, mission: Mission, param: Param):
-        self.mission, self.param = mission, param
+    def __init__(self, mission: Mission, param: Param, ctx: "Context" = None):
+        self.mission, self.param, self.ctx = mission, param, ctx
         self.last_error = ""
         self.rc = 0
 
     def update(self, log: bool, plan: PlanResult) -> bool:
         m, p, pl = self.mission.c_struct(), self.param.c_struct(), plan.c_struct()
-        self.rc = lib().rbp_planner_update(C.byref(m), C.byref(p), C.byref(pl))
+        if self.ctx is not None:
+            self.rc = lib().rbp_ctx_planner_update(self.ctx._h, C.byref(m), C.byref(p), C.byref(pl))
+        else:
+            self.rc = lib().rbp_planner_update(C.byref(m), C.byref(p), C.byref(pl))
         plan.sync_from(pl)
         self.last_error = "" if self.rc == 0 else ERROR_TEXT.get(self.rc, str(self.rc)) + " | " + last_error()
         return self.rc == 0
 
 
 class Session:
-    """K independent missions resident in HBM (e.g. the 50-map sweep of swarm_traj_planner_rbp_test_all.cpp:49-103)."""
+    """K independent missions resident in HBM (e.g. the 50-map sweep of swarm_traj_planner_rbp_test_all.cpp:49-103).
+    The missions share N; every plan keeps its own M (= ECBS makespan + 2) and max_boxes."""
 
     def __init__(self, worlds, missions, param: Param, plans, device=0):
         K = len(plans)

@@ -12,10 +12,8 @@ usage: python -m swarm_simulator_amd.test_all [--mission mission_64agents_15.jso
 import argparse
 import time
 
-import numpy as np
-
 from . import host, planner
-from .types import Param, PlanResult
+from .types import Param
 
 
 def parse_maps(spec: str):
@@ -26,19 +24,6 @@ def parse_maps(spec: str):
             out += list(range(int(a), int(b) + 1))
         else:
             out.append(int(part))
-    return out
-
-
-def pad_to(plans, M, time_step):
-    """a session needs one common M: repeat the goal waypoint (ecbs_planner.hpp:63-68 does the same for early arrivals)"""
-    out = []
-    for p in plans:
-        if p.M < M:
-            pad = M - p.M
-            traj = np.concatenate([p.init_traj, np.repeat(p.init_traj[:, -1:, :], pad, axis=1)], axis=1)
-            T = np.concatenate([p.T, p.T[-1] + time_step * np.arange(1, pad + 1)])
-            p = PlanResult(traj, T)
-        out.append(p)
     return out
 
 
@@ -85,8 +70,7 @@ def main(argv=None):
             report(i, mission, param, pr, args.csv)
         worlds.append(w), plans.append(pr), ok_maps.append(i)
     if args.mode == "batched":
-        M = max(p.M for p in plans)
-        plans = pad_to(plans, M, param.time_step)
+        # every map keeps its own M = makespan + 2 (ecbs_planner.hpp:41-43): the session is ragged, nothing is padded
         sess = planner.Session(worlds, [mission] * len(plans), param, plans)
         t0 = time.perf_counter()
         sess.run()

@@ -151,6 +151,8 @@ class PlanResult:
         self.total_cost = 0.0
         self.x_size = self.eq_size = self.ineq_size = 0
         self.qp_iterations = 0
+        self.qp_solves = self.qp_unpolished = 0
+        self.kkt_max = 0.0
         self._c = None
 
     def c_struct(self):
@@ -176,6 +178,7 @@ class PlanResult:
         self.time_scale, self.total_cost = p.time_scale, p.total_cost
         self.x_size, self.eq_size, self.ineq_size = p.x_size, p.eq_size, p.ineq_size
         self.qp_iterations = p.qp_iterations
+        self.qp_solves, self.qp_unpolished, self.kkt_max = p.qp_solves, p.qp_unpolished, p.kkt_max
 
     def clone_inputs(self):
         return PlanResult(self.init_traj.copy(), self.T.copy(), self.max_boxes)

@@ -1,0 +1,342 @@
+"""An INDEPENDENT restatement of the reference's batch QP, used to certify solver answers.  TEST INFRASTRUCTURE ONLY.
+
+numpy / scipy only.  Imports nothing from oracle/ and nothing from the product package: it takes plain arrays.
+
+What it restates (reference: swarm_planner/include/rbp_planner.hpp):
+    build_Q_base :327-347, build_Q_p :349-351, build_Aeq_base :353-405, build_deq :408-432, build_dlq :435-511 (box and
+    RSFC-normal selection by end time), build_dummy :513-549, setBatch / isQuadInBatch :849-881 and populatebyrow :551-688
+    -- in the REFERENCE's variable order  x[k * offset_dim + bi * offset_quad + m * (n+1) + i]  (:552-561), as explicit
+    matrices  (Q, Aeq, deq, G, h):   minimise x'Qx (no 1/2, :582-605)   s.t.  Aeq x = deq,  G x <= h.
+
+What it certifies.  The batch QP is convex with a unique optimum on its feasible set, so an answer x is THE
+answer iff the KKT conditions hold.  `certify_batch` takes a solver's x and
+    1. checks primal feasibility of x on every row;
+    2. reads the active set  A = {rows with slack <= tau}  off x  (the only thing taken from the solver);
+    3. RE-DERIVES the optimum of  min x'Qx  s.t. Aeq x = deq, G_A x = h_A  by dense float64 linear algebra (null-space
+       method with SVD rank decisions: a path that shares nothing with the interior-point / block-Cholesky / Lawson-Hanson
+       code of the GPU kernel or of oracle/planner.c), checks that this point is feasible for ALL rows and
+    4. that multipliers lambda >= 0 on A exist (non-negative least squares on the reduced stationarity equations).
+    Steps 3+4 prove x_as is the optimum; ||x - x_as||_inf is then the solver's true forward error.
+`certify_plan` walks the Gauss-Seidel schedule of solveQP (:140-203) for plan/iteration = 1: batch l is solved against the
+final control points of batches < l and the initial `dummy` of batches > l, which is reconstructible from the final answer.
+
+Run as a script it writes tests/golden/kkt_reference_c1.npz: the explicit matrices of the 4-agent C1 joint QP, so that the
+restatement itself is pinned against silent edits (tests/test_kkt_reference.py compares).
+"""
+import numpy as np
+from scipy.optimize import nnls
+
+N_DEG, PHI, OUTDIM = 5, 3, 3
+
+
+def Q_base():
+    """rbp_planner.hpp:330-335"""
+    return np.array([[720, -1800, 1200, 0, 0, -120],
+                     [-1800, 4800, -3600, 0, 600, 0],
+                     [1200, -3600, 3600, -1200, 0, 0],
+                     [0, 0, -1200, 3600, -3600, 1200],
+                     [0, 600, 0, -3600, 4800, -1800],
+                     [-120, 0, 0, 1200, -1800, 720]], dtype=np.float64)
+
+
+def A_0_T():
+    """rbp_planner.hpp:362-374"""
+    A0 = np.array([[1, 0, 0, 0, 0, 0], [-1, 1, 0, 0, 0, 0], [1, -2, 1, 0, 0, 0], [-1, 3, -3, 1, 0, 0], [1, -4, 6, -4, 1, 0],
+                   [-1, 5, -10, 10, -5, 1]], dtype=np.float64)
+    AT = np.array([[0, 0, 0, 0, 0, 1], [0, 0, 0, 0, -1, 1], [0, 0, 0, 1, -2, 1], [0, 0, -1, 3, -3, 1], [0, 1, -4, 6, -4, 1],
+                   [-1, 5, -10, 10, -5, 1]], dtype=np.float64)
+    return A0, AT
+
+
+def Aeq_base(T):
+    """rbp_planner.hpp:353-405: (2 phi + (M-1) phi) x M (n+1)"""
+    T = np.asarray(T, np.float64)
+    M, n, phi = len(T) - 1, N_DEG, PHI
+    A0, AT = A_0_T()
+    A = np.zeros((2 * phi + (M - 1) * phi, M * (n + 1)))
+    nn = 1
+    for i in range(phi):  # :380-387
+        A[i, 0:n + 1] = (T[1] - T[0]) ** (-i) * nn * A0[i]
+        A[phi + i, (n + 1) * (M - 1):(n + 1) * M] = (T[M] - T[M - 1]) ** (-i) * nn * AT[i]
+        nn *= (n - i)
+    for m in range(1, M):  # :390-399
+        nn = 1
+        for j in range(phi):
+            r = 2 * phi + phi * (m - 1) + j
+            A[r, (n + 1) * (m - 1):(n + 1) * m] = (T[m] - T[m - 1]) ** (-j) * nn * AT[j]
+            A[r, (n + 1) * m:(n + 1) * (m + 1)] = -(T[m + 1] - T[m]) ** (-j) * nn * A0[j]
+            nn *= (n - j)
+    return A
+
+
+def deq_agent(start9, goal9, M):
+    """rbp_planner.hpp:408-432 for one agent: (2 phi + (M-1) phi) x 3"""
+    d = np.zeros((2 * PHI + (M - 1) * PHI, OUTDIM))
+    for k in range(OUTDIM):
+        d[0, k], d[1, k], d[2, k] = start9[k], start9[k + 3], start9[k + 6]
+        d[PHI, k], d[PHI + 1, k], d[PHI + 2, k] = goal9[k], goal9[k + 3], goal9[k + 6]
+    return d
+
+
+def select_boxes(T, sfc_box, sfc_time, sfc_count):
+    """rbp_planner.hpp:447-469: per (agent, segment) the first box whose end time is not before T[m+1].
+    Returns lo, hi [N][M][3]."""
+    N, M = len(sfc_count), len(T) - 1
+    lo, hi = np.zeros((N, M, 3)), np.zeros((N, M, 3))
+    for qi in range(N):
+        bi = 0
+        for m in range(M):
+            while bi < sfc_count[qi] and sfc_time[qi, bi] < T[m + 1]:
+                bi += 1
+            b = min(bi, sfc_count[qi] - 1)  # the reference would read past the end here; guarded like every restatement
+            lo[qi, m], hi[qi, m] = sfc_box[qi, b, 0:3], sfc_box[qi, b, 3:6]
+    return lo, hi
+
+
+def select_normals(T, rsfc_normal, rsfc_time):
+    """rbp_planner.hpp:483-497: per (pair, segment) the first RSFC entry whose time is not before T[m+1].  With
+    RSFC times = T[1..M] (rbp_corridor.hpp:390) this is the identity; kept literal."""
+    npair, M = rsfc_normal.shape[0], len(T) - 1
+    out = np.zeros((npair, M, 3))
+    for m in range(M):
+        ri = 0
+        while ri < M and rsfc_time[ri] < T[m + 1]:
+            ri += 1
+        out[:, m] = rsfc_normal[:, min(ri, M - 1)].astype(np.float64)
+    return out
+
+
+def build_dummy(init_traj):
+    """rbp_planner.hpp:513-549: [N][6M][3]; first three control points of segment m = waypoint m, last three = waypoint m+1"""
+    tr = np.asarray(init_traj, np.float32).astype(np.float64)
+    N, P, _ = tr.shape
+    M = P - 1
+    d = np.zeros((N, 6 * M, 3))
+    for m in range(M):
+        d[:, 6 * m:6 * m + 3] = tr[:, m:m + 1]
+        d[:, 6 * m + 3:6 * m + 6] = tr[:, m + 1:m + 2]
+    return d
+
+
+def batches(N, sequential, batch_size, batch_iter):
+    """setBatch :849-872.  Returns (list of agent lists, number of batches solved per pass)."""
+    if sequential:
+        bmax = int(np.ceil(N / batch_size))
+        if batch_iter < 0 or batch_iter > bmax:
+            batch_iter = bmax
+    else:
+        bmax = int(np.ceil(N / batch_size))  # sized with the ORIGINAL batch_size (:850), then batch_size := N
+        batch_size, batch_iter = N, 1
+    b = [[] for _ in range(max(bmax, 1))]
+    for qi in range(N):
+        b[qi // batch_size].append(qi)
+    return b, batch_iter
+
+
+def pair_index(N, qi, qj):
+    return qi * N - qi * (qi + 1) // 2 + (qj - qi - 1)
+
+
+class BatchQP:
+    """populatebyrow :551-688 for batch l as explicit dense/structured data in the reference's variable order."""
+
+    def __init__(self, T, start, goal, radius, lo, hi, normals, dummy, batch):
+        T = np.asarray(T, np.float64)
+        N, M = start.shape[0], len(T) - 1
+        n1, oq = N_DEG + 1, (N_DEG + 1) * M
+        nb = len(batch)
+        self.batch, self.M, self.nb = list(batch), M, nb
+        offset_quad, offset_dim = oq, nb * oq
+        self.nx = OUTDIM * offset_dim
+        var = lambda k, bi, j: k * offset_dim + bi * offset_quad + j
+        self.var = var
+        # objective: block diagonal Q_p per (k, bi, m)   :582-605
+        Qb = Q_base()
+        self.Qseg = np.stack([Qb * (T[m + 1] - T[m]) ** (-2 * PHI + 1) for m in range(M)])  # [M][6][6]
+        # equalities :608-622 -- Aeq_base per (k, bi), rhs from deq
+        self.Ab = Aeq_base(T)
+        ne = self.Ab.shape[0]
+        self.deq = np.zeros(OUTDIM * nb * ne)
+        for k in range(OUTDIM):
+            for bi, qi in enumerate(batch):
+                self.deq[(k * nb + bi) * ne:(k * nb + bi + 1) * ne] = deq_agent(start[qi], goal[qi], M)[:, k]
+        # inequalities, G x <= h, as (row -> list of (col, val)) in COO form
+        rows, cols, vals, h = [], [], [], []
+        r = 0
+        for k in range(OUTDIM):  # SFC :626-635
+            for bi, qi in enumerate(batch):
+                for j in range(oq):
+                    m = j // n1
+                    rows += [r, r + 1],
+                    cols += [var(k, bi, j), var(k, bi, j)],
+                    vals += [1.0, -1.0],
+                    h += [hi[qi, m, k], -lo[qi, m, k]]
+                    r += 2
+        rows = [x for pr in rows for x in pr]
+        cols = [x for pr in cols for x in pr]
+        vals = [x for pr in vals for x in pr]
+        self.n_sfc = r
+        inb = {qi: bi for bi, qi in enumerate(batch)}
+        for qi in range(N):  # RSFC :638-684
+            for qj in range(qi + 1, N):
+                bi, bj = inb.get(qi, -1), inb.get(qj, -1)
+                if bi < 0 and bj < 0:
+                    continue
+                nv = normals[pair_index(N, qi, qj)]  # [M][3]
+                rr = radius[qi] + radius[qj]
+                for j in range(oq):
+                    nrm = nv[j // n1]
+                    if bi >= 0 and bj < 0:    # n.(dummy_j - x_i) >= rr   ->   n.x_i <= n.dummy_j - rr
+                        for k in range(OUTDIM):
+                            rows.append(r), cols.append(var(k, bi, j)), vals.append(nrm[k])
+                        h.append(float(nrm @ dummy[qj, j]) - rr)
+                    elif bi < 0 and bj >= 0:  # n.(x_j - dummy_i) >= rr   ->  -n.x_j <= -n.dummy_i - rr
+                        for k in range(OUTDIM):
+                            rows.append(r), cols.append(var(k, bj, j)), vals.append(-nrm[k])
+                        h.append(-float(nrm @ dummy[qi, j]) - rr)
+                    else:                     # n.(x_j - x_i) >= rr       ->   n.x_i - n.x_j <= -rr
+                        for k in range(OUTDIM):
+                            rows.append(r), cols.append(var(k, bi, j)), vals.append(nrm[k])
+                            rows.append(r), cols.append(var(k, bj, j)), vals.append(-nrm[k])
+                        h.append(-rr)
+                    r += 1
+        self.n_ineq = r
+        self.g_rows, self.g_cols, self.g_vals = np.array(rows), np.array(cols), np.array(vals, np.float64)
+        self.h = np.array(h, np.float64)
+        self.count_x, self.count_eq, self.count_lq = self.nx, OUTDIM * nb * ne, self.n_ineq  # :579, :623, :687
+
+    # ---- operators -----------------------------------------------------------------------------------------------
+    def x_of(self, ctrl):
+        """ctrl [N][3][6M] (the C ABI's layout) -> x in the reference's variable order"""
+        return np.concatenate([ctrl[qi, k] for k in range(OUTDIM) for qi in self.batch])
+
+    def Qx(self, x):
+        X = x.reshape(OUTDIM * self.nb, self.M, 6)
+        return np.einsum("mij,umj->umi", self.Qseg, X).reshape(-1)
+
+    def objective(self, x):
+        return float(x @ self.Qx(x))
+
+    def G_dot(self, x):
+        out = np.zeros(self.n_ineq)
+        np.add.at(out, self.g_rows, self.g_vals * x[self.g_cols])
+        return out
+
+    def G_dense_rows(self, idx):
+        """dense rows idx of G"""
+        pos = {r: i for i, r in enumerate(idx)}
+        sel = np.isin(self.g_rows, idx)
+        Gd = np.zeros((len(idx), self.nx))
+        for r, c, v in zip(self.g_rows[sel], self.g_cols[sel], self.g_vals[sel]):
+            Gd[pos[r], c] += v
+        return Gd
+
+    def eq_residual(self, x):
+        ne = self.Ab.shape[0]
+        X = x.reshape(OUTDIM * self.nb, -1)
+        return (X @ self.Ab.T).reshape(-1) - self.deq
+
+
+def _nullspace(A, rtol=1e-11):
+    U, s, Vt = np.linalg.svd(A, full_matrices=True)
+    rank = int((s > rtol * s[0]).sum()) if s.size else 0
+    return Vt[rank:].T, rank
+
+
+def certify_batch(qp: BatchQP, x, tau=2e-8):
+    """see the module docstring.  Returns a dict of residuals; nothing is asserted here."""
+    nb, M = qp.nb, qp.M
+    nu = OUTDIM * nb
+    # equality elimination: x = x0 + Z u per (k, bi) block with the SAME Aeq_base
+    Zb, _ = _nullspace(qp.Ab)                       # 6M x (6M - 3(M+1))
+    Ab_pinv = np.linalg.pinv(qp.Ab)
+    ne, oq, nz = qp.Ab.shape[0], qp.Ab.shape[1], Zb.shape[1]
+    x0 = (qp.deq.reshape(nu, ne) @ Ab_pinv.T).reshape(-1)
+    slack = qp.h - qp.G_dot(x)
+    out = {"viol_eq": float(np.abs(qp.eq_residual(x)).max()), "viol_ineq": float(max(0.0, -slack.min())),
+           "objective": qp.objective(x)}
+    act = np.nonzero(slack <= tau)[0]
+    out["n_active"] = int(len(act))
+    # reduced problem in u:  min (x0 + Z u)' Q (x0 + Z u)  s.t.  (G_A Z) u = h_A - G_A x0
+    def Zt(v):   # Z' v
+        return (v.reshape(nu, oq) @ Zb).reshape(-1)
+    def Zm(u):   # Z u
+        return (u.reshape(nu, nz) @ Zb.T).reshape(-1)
+    # reduced Hessian: block diagonal, the same block for every (k, bi):  Zb' (2 Q) Zb
+    Qfull = np.zeros((oq, oq))
+    for m in range(M):
+        Qfull[6 * m:6 * m + 6, 6 * m:6 * m + 6] = qp.Qseg[m]
+    Hb = Zb.T @ (2 * Qfull) @ Zb
+    g0 = Zt(2 * qp.Qx(x0))
+    if len(act):
+        GA = qp.G_dense_rows(act)
+        GAZ = (GA.reshape(len(act), nu, oq) @ Zb).reshape(len(act), nu * nz)
+        rhs = qp.h[act] - GA @ x0
+        u_p, *_ = np.linalg.lstsq(GAZ, rhs, rcond=1e-12)
+        out["active_rows_inconsistency"] = float(np.abs(GAZ @ u_p - rhs).max())
+        Nn, rank = _nullspace(GAZ)
+        out["active_rank"] = rank
+    else:
+        GAZ = np.zeros((0, nu * nz))
+        u_p = np.zeros(nu * nz)
+        Nn = np.eye(nu * nz)
+    Hu = lambda u: (u.reshape(nu, nz) @ Hb).reshape(-1)   # H u (H block diagonal, Hb symmetric)
+    HN = np.stack([Hu(Nn[:, i]) for i in range(Nn.shape[1])], axis=1) if Nn.shape[1] else np.zeros((nu * nz, 0))
+    NHN = Nn.T @ HN
+    gred = Nn.T @ (Hu(u_p) + g0)
+    w = np.linalg.solve(NHN, -gred) if Nn.shape[1] else np.zeros(0)
+    u_as = u_p + Nn @ w
+    x_as = x0 + Zm(u_as)
+    out["x_as"] = x_as
+    out["forward_error"] = float(np.abs(x - x_as).max())
+    slack_as = qp.h - qp.G_dot(x_as)
+    out["x_as_viol_ineq"] = float(max(0.0, -slack_as.min()))
+    out["x_as_viol_eq"] = float(np.abs(qp.eq_residual(x_as)).max())
+    out["objective_as"] = qp.objective(x_as)
+    # multipliers: (G_A Z)' lambda = -(H u_as + g0), lambda >= 0
+    grad = Hu(u_as) + g0
+    gscale = float(np.abs(Zt(2 * np.abs(qp.Qx(np.abs(x_as))))).max()) + 1.0
+    if len(act):
+        lam, rn = nnls(GAZ.T, -grad, maxiter=20 * GAZ.shape[0] + 200)
+        out["stationarity"] = float(np.abs(GAZ.T @ lam + grad).max() / gscale)
+        out["lambda_max"] = float(lam.max()) if lam.size else 0.0
+        out["complementarity"] = float((lam * np.maximum(slack_as[act], 0)).max()) if lam.size else 0.0
+    else:
+        out["stationarity"] = float(np.abs(grad).max() / gscale)
+        out["lambda_max"] = 0.0
+        out["complementarity"] = 0.0
+    return out
+
+
+def certify_plan(T0, init_traj, start, goal, radius, sfc_box, sfc_time, sfc_count, rsfc_normal, rsfc_time, ctrl, sequential,
+                 batch_size, batch_iter, tau=2e-8, only_batches=None):
+    """plan/iteration = 1: every batch QP of solveQP's single pass, reconstructed from the FINAL control points `ctrl`
+    ([N][3][6M]): frozen agents of batches < l at their final values, of batches > l at build_dummy.  Returns one report per batch."""
+    T0 = np.asarray(T0, np.float64)
+    N = start.shape[0]
+    lo, hi = select_boxes(T0, sfc_box, sfc_time, sfc_count)
+    normals = select_normals(T0, rsfc_normal, rsfc_time)
+    dummy = build_dummy(init_traj)
+    bl, biter = batches(N, sequential, batch_size, batch_iter)
+    reports = []
+    for l in range(biter):
+        for qi in bl[l]:  # never read for in-batch agents; set only so that the state after the loop equals solveQP's :183-185
+            pass
+        if only_batches is None or l in only_batches:
+            qp = BatchQP(T0, start, goal, radius, lo, hi, normals, dummy, bl[l])
+            rep = certify_batch(qp, qp.x_of(ctrl), tau)
+            rep["batch"] = l
+            rep["count_x"], rep["count_eq"], rep["count_lq"] = qp.count_x, qp.count_eq, qp.count_lq
+            reports.append(rep)
+        for qi in bl[l]:  # dummy <- vals  (:183-185)
+            dummy[qi] = ctrl[qi].T
+    return reports
+
+
+if __name__ == "__main__":
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "c1_4agents_empty_joint.npz"))
+    import json
+    # mission geometry of the C1 case: start/goal come with the golden's mission file; only arrays are used here
+    raise SystemExit("the C1 matrix fixture is written by tests/golden/make_golden.py --kkt (needs the mission loader)")
