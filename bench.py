@@ -3,18 +3,25 @@
 
 A "step" is one pass of the hot path (Corridor::update + RBPPlanner::update equivalents) over one batch of
 missions: the reference's own benchmark shape, the map sweep of swarm_traj_planner_rbp_test_all.cpp:49-103
-(64-agent mission x worlds/map*.bt, launch/plan_rbp_test.launch:27-59: sequential=true, batch_size=4).  The ECBS
+(64-agent mission x worlds/map*.bt, launch/plan_rbp_test.launch:27-59: sequential=true, batch_size=4).  Every map keeps
+its own M = ECBS makespan + 2 (ecbs_planner.hpp:41-43): the session is ragged, nothing is padded.  The ECBS
 front-end, map loading and the EDT are NOT in the metric and run once, untimed; inputs (distance
 grids, initTraj, mission) are resident in HBM when the timed region starts.
 
 Multi-GPU: missions are independent, so ranks take disjoint slices of the sweep with no data-path collective
 (weak scaling: every rank gets --missions-per-gpu missions); value = missions of all ranks * N / max-over-ranks time.
+`--gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks.
+
+`--config c4` times ONE 256-agent mission whose Corridor::update is sharded by agent over the ranks (one fused RCCL
+all-gather) followed by the planner sweep (BASELINE.json config 4).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,20 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD public spec for MI355X FP64 matrix (not in the local guides)
+
+CONFIGS = {  # BASELINE.json configs -> flags (C1 is the CPU plumbing case of the test-suite)
+    "c2": dict(agents=16), "c3": dict(agents=64), "c5": dict(agents=64, batch_size=8, iteration=50, missions_per_gpu=250),
+    "c4": dict(agents=256),
+}
+
+
+def kernel_source_sha():
+    """hash of the HIP sources the QP / corridor kernels are built from: ties a profiles/*_pmc.json to the code it measured"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def shard_missions(n_per_rank: int, rank: int, world_size: int, n_maps: int = 50):
@@ -56,27 +77,93 @@ def build_inputs(map_ids, n_agents, param):
             cache[mid] = (w, host.ecbs_plan(w, m, param))
         w, pr = cache[mid]
         worlds.append(w)
-        plans.append(pr.clone_inputs())
-    # every map keeps its own M = ECBS makespan + 2 (ecbs_planner.hpp:41-43): the session is ragged, nothing is padded
-    out = plans
-    return m, worlds, out
+        plans.append(pr.clone_inputs())   # every map keeps its own M = makespan + 2: a ragged session, nothing is padded
+    return m, worlds, plans
 
 
-def cpu_baseline(mission, param, world, plan, budget_s=20.0):
-    """the CPU oracle (a port: CPLEX is proprietary and absent) timed on this box's host cores, one thread,
-    on ONE mission of the same workload (SFC + RSFC + QP), bounded to ~budget_s."""
+# ---- CPU baseline: the oracle (a port: CPLEX is proprietary and absent), timed on this box's host cores -------------------------
+def _cpu_one(args):
+    """one mission of the workload on one core: corridor + planner of the oracle.  Returns (agents, seconds, stage split, report)."""
+    mid, n_agents, pkw = args
+    from swarm_simulator_amd import host
+    from swarm_simulator_amd.types import Param
     from tests import oracle_lib as O
-    pr = plan.clone_inputs()
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission(f"mission_{n_agents}agents_15.json")
+    w = host.load_world(f"map{mid}.bt", p)
+    pr = host.ecbs_plan(w, m, p)
     t0 = time.perf_counter()
-    rc, ns = O.corridor_update(world, mission, param, pr)
+    rc, _ = O.corridor_update(w, m, p, pr)
     t1 = time.perf_counter()
-    rc2, rep = O.planner_update(mission, param, pr)
+    rc2, rep = O.planner_update(m, p, pr)
     t2 = time.perf_counter()
-    ok = rc == 0 and rc2 == 0
-    return {"value": (mission.qn / (t2 - t0)) if ok else None, "unit": "agent-trajectories/s", "cores": 1, "kind": "port",
-            "sample": f"1 mission ({mission.qn} agents, M={pr.M}): corridor {t1 - t0:.3f}s + planner {t2 - t1:.3f}s "
-                      f"({rep['n_qp']} batch QPs, {rep['iters_total']} IPM iterations, own IPM+active-set in place of CPLEX)",
-            "host_cores_available": os.cpu_count()}, ns
+    return m.qn, t2 - t0, t1 - t0, t2 - t1, rc == 0 and rc2 == 0, rep["n_qp"], rep["iters_total"], pr.M
+
+
+def cpu_baseline(n_agents, pkw, budget_s=25.0):
+    """measured twice: ONE thread on one mission of the workload, and ALL host cores with one mission per core
+    (the missions of the sweep are independent: a process pool over maps), bounded to about `budget_s` of wall time."""
+    from concurrent.futures import ProcessPoolExecutor
+    one = _cpu_one((1, n_agents, pkw))
+    n1, s1, sc, sp, ok, nqp, its, M = one
+    out = {"value": (n1 / s1) if ok else None, "unit": "agent-trajectories/s", "cores": 1, "kind": "port",
+           "sample": f"1 mission (map1, {n1} agents, M={M}): corridor {sc:.3f}s + planner {sp:.3f}s ({nqp} batch QPs, {its} IPM "
+                     f"iterations, own IPM+active-set in place of CPLEX)"}
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 256))
+    rounds = max(1, int((budget_s - s1) // max(s1 * 1.5, 1e-3)))  # a loaded box runs each mission slower than the lone one
+    n_missions = workers * min(rounds, 2)
+    try:
+        t0 = time.perf_counter()
+        with ProcessPoolExecutor(max_workers=workers) as ex:
+            res = list(ex.map(_cpu_one, [((i % 50) + 1, n_agents, pkw) for i in range(n_missions)], chunksize=1))
+        dt = time.perf_counter() - t0
+        good = [r for r in res if r[4]]
+        out["all_cores"] = {"value": sum(r[0] for r in good) / dt, "unit": "agent-trajectories/s", "cores": workers,
+                            "sample": f"{len(good)} missions (maps 1..{min(50, n_missions)}, one per process, {workers} processes) in {dt:.1f}s "
+                                      f"wall incl. process start, grid build and ECBS of each worker"}
+    except Exception as e:  # the pool is optional equipment of the bench
+        out["all_cores"] = {"value": None, "cores": workers, "sample": f"failed: {e}"}
+    out["host_cores_available"] = cores
+    return out
+
+
+def single_mission_latency(mission, param, world, plan, reps=3):
+    """the reference's call shape: ONE mission through the two synchronous host-buffer calls (upload + kernels + download each),
+    device memory kept in a context.  Returns milliseconds (min over reps) for corridor, planner and the fused one-call form."""
+    from swarm_simulator_amd import planner
+    ctx = planner.Context()
+    best = [1e30, 1e30, 1e30]
+    for _ in range(reps):
+        pr = plan.clone_inputs()
+        t0 = time.perf_counter()
+        ok1 = planner.Corridor(world, mission, param, ctx).update(False, pr)
+        t1 = time.perf_counter()
+        ok2 = planner.RBPPlanner(mission, param, ctx).update(False, pr)
+        t2 = time.perf_counter()
+        pr2 = plan.clone_inputs()
+        rc = ctx.plan_update(world, mission, param, pr2)
+        t3 = time.perf_counter()
+        if not (ok1 and ok2 and rc == 0):
+            return None
+        best = [min(best[0], 1e3 * (t1 - t0)), min(best[1], 1e3 * (t2 - t1)), min(best[2], 1e3 * (t3 - t2))]
+    ctx.close()
+    return {"corridor_update_ms": best[0], "planner_update_ms": best[1], "two_calls_ms": best[0] + best[1], "fused_plan_update_ms": best[2],
+            "note": "one mission (map1) alone on the GPU, host buffers in and out (H2D/D2H included), min of %d" % reps}
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` outside a torchrun environment: run the same command line with N ranks, one per GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -84,6 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json configuration shortcut (sets the flags below)")
     ap.add_argument("--agents", type=int, default=64, help="mission_<N>agents_15.json (64 = headline, 16 = C2)")
     ap.add_argument("--missions-per-gpu", type=int, default=2000,
                     help="missions resident per step on each GPU: 2000 = forty passes of the reference's 50-map sweep (one "
@@ -93,7 +181,15 @@ def main():
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of the launcher)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher test: initialise the ranks, print the JSON skeleton, plan nothing")
     args = ap.parse_args()
+    if args.config:
+        for k, v in CONFIGS[args.config].items():
+            setattr(args, k, v)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_torchrun(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,8 +199,22 @@ def main():
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world_size)
+    n_ranks = dist.get_world_size() if dist is not None else 1   # what the collective library actually sees
+    if args.gpus != n_ranks and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but {n_ranks} rank(s) were launched; reporting n_gpus={n_ranks}", file=sys.stderr)
+    if args.dry_run:
+        n_total, secs = aggregate(args.missions_per_gpu * args.agents, 1.0, dist)
+        if rank == 0:
+            print(json.dumps({"metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": None, "n_gpus": n_ranks, "dry_run": True,
+                              "agents_all_ranks": n_total, "maps_rank0": shard_missions(min(args.missions_per_gpu, 4), rank, n_ranks)}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the RBP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -113,10 +223,14 @@ def main():
     from swarm_simulator_amd import _abi as A
     from swarm_simulator_amd.types import Param
 
-    param = Param.test_sweep(batch_size=args.batch_size, iteration=args.iteration, sequential=not args.joint)
-    map_ids = shard_missions(args.missions_per_gpu, rank, world_size)
+    pkw = dict(batch_size=args.batch_size, iteration=args.iteration, sequential=not args.joint)
+    param = Param.test_sweep(**pkw)
+    if args.config == "c4":
+        return bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist)
+    map_ids = shard_missions(args.missions_per_gpu, rank, n_ranks)
     mission, worlds, plans = build_inputs(map_ids, args.agents, param)
-    K, N, M = len(plans), mission.qn, plans[0].M
+    K, N = len(plans), mission.qn
+    Ms = sorted({p.M for p in plans})
     sess = planner.Session(worlds, [mission] * K, param, plans, device=local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -129,14 +243,6 @@ def main():
     torch.cuda.synchronize()
     status = sess.download(stream)
     variant = os.environ.get("RBP_QP_VARIANT", "auto")
-    if any(status) and variant == "auto":
-        # the library picks the 128-VGPR build (two workgroups per CU) for this many missions; if that build ever fails a
-        # mission the bench falls back to the 256-VGPR build rather than reporting nothing (and says so in `config`)
-        os.environ["RBP_QP_VARIANT"] = "w2"
-        variant = "w2 (fallback: the 128-VGPR build failed a mission)"
-        step()
-        torch.cuda.synchronize()
-        status = sess.download(stream)
     if any(status):
         raise SystemExit(f"rank {rank}: missions failed with status {[x for x in status if x][:8]}")
     if dist is not None:
@@ -161,50 +267,117 @@ def main():
     planner_ms = float(np.mean([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)]))
     ct = sess.counters(stream)  # of the last step
     status = sess.download(stream)
+    unpolished = int(sum(p.qp_unpolished for p in plans))
 
     if rank == 0:
         value = n_total / secs
-        # dominant kernel: the batch QP kernel, ONE launch per step (every workgroup runs its mission's whole batch
-        # schedule).  Algorithmic work per launch = flops of the dense block factorisations/solves it logs (SURVEY.md 8d:
-        # F = sum_factor 7/3 nk^3 per knot + sum_solve 4 nk^2 per knot); achieved = flops per launch / planner-stage time
-        # (HIP events on the launch stream; the stage is the QP launch plus three sub-millisecond helper kernels).
+        # dominant kernel: the batch QP kernel, ONE launch per step (every workgroup runs its mission's whole batch schedule).
+        # Two roofs are reported for it:
+        #  * HBM (the binding one: arithmetic intensity ~0.3 flop/B): ALGORITHMIC bytes per launch = the row state / row constants
+        #    every sweep streams and the knot blocks every factorisation / substitution reads and writes, counted by the kernel
+        #    itself (rbp_counters.qp_row_bytes), / planner-stage time (HIP events on the launch stream);
+        #  * FP64 MFMA: flops of the dense block factorisations / solves it logs.
+        # `traffic` = HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+        # command (profiles/r02_pmc.json); printed only when that file was collected from the kernel sources of this build.
         qp_tflops = ct["qp_flops"] / (planner_ms * 1e-3) / 1e12
-        # HBM-side bytes per qp_batch_kernel launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc.json
-        traffic = None
+        qp_gbs = ct["qp_row_bytes"] / (planner_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-            if pmc.get("missions_per_gpu") == K and N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+            same = (pmc.get("missions_per_gpu") == K and pmc.get("kernel_source_sha") == kernel_source_sha() and N == 64 and
+                    args.batch_size == 4 and args.iteration == 1 and not args.joint)
+            if same:
                 traffic = pmc["kernels"]["qp_batch_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc.json"
         except Exception:
             pass
         sfc_bytes = 4.0 * ct["sfc_samples"]
         out = {
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "the reference's own mission JSONs and octomap worlds (data/, committed copies of swarm_planner/missions and worlds); "
+                    "initTraj from the repository's own ECBS front-end; no padding",
             "config": {"workload": f"{N}-agent random_forest mission (mission_{N}agents_15.json) on worlds/map1..50.bt, {K} "
-                                   f"missions in flight per GPU ({K / 50:g} passes of the 50-map sweep), sequential={str(not args.joint).lower()} "
+                                   f"missions in flight per GPU ({K / 50:g} passes of the 50-map sweep), every map with its own "
+                                   f"M = makespan + 2 (M in {Ms}, no padding), sequential={str(not args.joint).lower()} "
                                    f"batch_size={args.batch_size} iteration={args.iteration} (plan_rbp_test.launch keys)",
-                       "agents": N, "segments": M, "missions_per_gpu": K, "parallelism": f"missions sharded over {world_size} GPU(s)",
-                       "all_missions_ok": not any(status), "qp_kernel_variant": variant},
+                       "agents": N, "segments": Ms, "missions_per_gpu": K, "parallelism": f"missions sharded over {n_ranks} GPU(s)",
+                       "all_missions_ok": not any(status), "qp_kernel_variant": variant, "baseline_config": args.config or "c3"},
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},
-            "roofline": {"bound": "mfma", "kernel": "qp_batch_kernel", "achieved": qp_tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "flops_per_step": ct["qp_flops"], "ipm_iterations_per_step": ct["qp_ipm_iters"],
-                         "constraint_rows_swept_per_step": ct["qp_constraint_rows"],
-                         "batch_qps_per_step": ct["qp_solves"], "batch_qps_polished_per_step": ct["qp_polished"]},
+            "roofline": {"bound": "hbm", "kernel": "qp_batch_kernel", "achieved": qp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": qp_gbs / HBM_PEAK_GBS, "hbm_frac": qp_gbs / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": ct["qp_row_bytes"], "traffic": traffic, "traffic_source": traffic_src,
+                         "mfma": {"achieved": qp_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS,
+                                  "flops_per_launch": ct["qp_flops"]},
+                         "ipm_iterations_per_step": ct["qp_ipm_iters"], "constraint_rows_swept_per_step": ct["qp_constraint_rows"],
+                         "batch_qps_per_step": ct["qp_solves"], "batch_qps_polished_per_step": ct["qp_polished"],
+                         "batch_qps_unpolished_per_step": unpolished, "kkt_max": ct["kkt_max"]},
             "roofline_sfc": {"bound": "hbm", "kernel": "sfc_kernel", "achieved": sfc_bytes / (corridor_ms * 1e-3) / 1e9,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s (reference-equivalent sample bytes, not physical)",
                              "frac": sfc_bytes / (corridor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "samples_per_step": ct["sfc_samples"]},
         }
+        if N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint:
+            try:
+                out["latency_ms_single_mission"] = single_mission_latency(mission, param, worlds[0], plans[0])
+            except Exception as e:
+                out["latency_ms_single_mission"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], _ = cpu_baseline(mission, param, worlds[0], plans[0])
+                out["cpu_baseline"] = cpu_baseline(args.agents, pkw)
             except Exception as e:  # the oracle is optional equipment of the bench
                 out["cpu_baseline"] = {"value": None, "unit": "agent-trajectories/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out))
     sess.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):
+    """BASELINE.json config 4: ONE 256-agent mission, Corridor::update sharded by agent over the ranks with one fused all-gather
+    (swarm_simulator_amd/sharded.py), then the planner sweep.  value = 256 agents * steps / wall time (max over ranks)."""
+    import torch
+    from swarm_simulator_amd import host, sharded
+    m = host.load_mission("mission_256agents_c4.json")
+    w = host.load_world("map1.bt", param)
+    init = host.ecbs_plan(w, m, param)
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        pr = init.clone_inputs()
+        t0 = time.perf_counter()
+        ok, err = sharded.plan_sharded(w, m, param, pr, dist, dev)
+        torch.cuda.synchronize()
+        return ok, err, time.perf_counter() - t0, pr
+
+    for _ in range(max(args.warmup, 1)):
+        ok, err, _, _ = step()
+        if not ok:
+            raise SystemExit(f"rank {rank}: C4 mission failed: {err}")
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok, err, _, pr = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    secs = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": m.qn * args.steps / secs, "unit": "agent-trajectories/s",
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "256-agent mission derived from the reference's 64-agent pattern (tools/make_mission_256.py; no such file upstream), worlds/map1.bt",
+            "config": {"workload": f"ONE {m.qn}-agent mission (M={pr.M}), Corridor::update sharded by agent over {n_ranks} rank(s) + one fused "
+                                   f"all-gather, RBPPlanner sweep sequential batch_size={args.batch_size}; host buffers in and out",
+                       "agents": m.qn, "segments": pr.M, "parallelism": f"agents sharded over {n_ranks} GPU(s) (corridor), planner sweep per rank",
+                       "baseline_config": "c4", "qp_unpolished": pr.qp_unpolished, "kkt_max": pr.kkt_max, "all_missions_ok": bool(ok)}}))
     if dist is not None:
         dist.destroy_process_group()
 

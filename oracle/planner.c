@@ -957,7 +957,7 @@ static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, dou
     int* P = (int*)malloc(sizeof(int) * cap);
     char* in_p = (char*)calloc(cap, 1);
     double* gx = (double*)malloc(sizeof(double) * nc);
-    int nV = 0, nP = 0, lh_iters = 0;
+    int nV = 0, nP = 0, lh_iters = 0, rejected = 0, redo = 0, drops = 0;
     if (kkt_factor(&K, w0)) goto out;
     kkt_solve(&K, r1, q->beq, x0, y0); /* K0 [x0;y0] = [0;b] */
     op_Gx(q, x0, gx);
@@ -1041,6 +1041,10 @@ static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, dou
         }
         /* primal point; iterative refinement of z on the active rows against the ACTUAL residual G_P x - h_P
          * (S and d were formed from V and x0, which carry the ~1e-9 relative error of solves with K0) */
+      for (int attempt = 0; attempt < 2 && rc; ++attempt) {
+        if (attempt == 0) memcpy(wv, zc, sizeof(double) * ncand); /* the Lawson-Hanson multipliers, before refinement */
+        else memcpy(zc, wv, sizeof(double) * ncand);              /* second attempt: verify them as they are */
+        const int last_round = attempt == 0 ? 4 : 0;
         for (int round = 0; round < 5; ++round) {
             memcpy(xn, x0, sizeof(double) * nx);
             for (int a = 0; a < nP; ++a) {
@@ -1048,7 +1052,7 @@ static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, dou
                 double zz = zc[P[a]];
                 for (int i = 0; i < nx; ++i) xn[i] -= zz * v[i];
             }
-            if (nP == 0 || round == 4) break;
+            if (nP == 0 || round == last_round) break;
             double rmax = 0;
             for (int a = 0; a < nP; ++a) {
                 int c = cand[P[a]];
@@ -1070,19 +1074,37 @@ static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, dou
             for (int a = 0; a < nP; ++a) zc[P[a]] += yv[a];
         }
         op_Gx(q, xn, gx);
-        double vmax = 0, zmin = 0;
+        double vmax = 0, zmin = 0, zmax = 0;
         int n_add = 0;
-        for (int a = 0; a < nP; ++a) zmin = fmin(zmin, zc[P[a]]);
+        for (int a = 0; a < nP; ++a) zmin = fmin(zmin, zc[P[a]]), zmax = fmax(zmax, zc[P[a]]);
         for (int c = 0; c < nc; ++c) {
             double v = gx[c] - q->h[c];
             if (v > vmax) vmax = v;
             if (v > 1e-11 && !in_c[c] && ncand < cap) cand[ncand++] = c, in_c[c] = 1, n_add++;
         }
         if (verbose)
-            printf("    polish round %d: candidates %d, active %d, LH iterations %d, max violation %.3e, added %d\n", outer,
-                   ncand - n_add, nP, lh_iters, vmax, n_add);
+            printf("    polish round %d: candidates %d, active %d, LH iterations %d, max violation %.3e, added %d, zmin %.3e zmax %.3e\n", outer,
+                   ncand - n_add, nP, lh_iters, vmax, n_add, zmin, zmax);
         if (n_add == 0) {
-            if (vmax > 1e-9 || zmin < -1e-9) break; /* not converged: reject */
+            /* feasibility 5e-9: rows numerically dependent on the active ones (lattice-aligned SFC faces against r_i + r_j rows)
+             * can stay inconsistent at the 1e-9 level whatever the active set; multipliers reach 1e3, so their sign test is
+             * relative.  (Both thresholds as in the HIP kernel's polish.) */
+            if (vmax > 5e-9 || zmin < -1e-9 * fmax(1.0, zmax)) { /* not converged */
+                if (attempt == 0 && vmax <= 5e-9 && drops < 8) {
+                    /* the refined multipliers say some active rows should not be active (the dual solve's S carries the ~1e-9
+                     * relative error of solves with K0): they leave, and Lawson-Hanson continues from the refined point */
+                    int keep = 0;
+                    for (int a = 0; a < nP; ++a) {
+                        if (zc[P[a]] < 0) zc[P[a]] = 0, in_p[P[a]] = 0;
+                        else P[keep++] = P[a];
+                    }
+                    nP = keep, drops++, redo = 1;
+                    break;
+                }
+                if (attempt == 0) continue; /* the refinement can push a multiplier of nearly dependent rows negative: verify the unrefined ones */
+                rejected = 1;
+                break;
+            }
             memcpy(yn, y0, sizeof(double) * ne);
             for (int a = 0; a < nP; ++a)
                 for (int e = 0; e < ne; ++e) yn[e] -= zc[P[a]] * Yv[(size_t)P[a] * ne + e];
@@ -1110,6 +1132,14 @@ static int qp_polish(const qp_t* q, int linear_solver, double* x, double* y, dou
             rc = 0;
             break;
         }
+        break; /* new candidates: extend V, S, d and solve the dual again */
+      }
+        if (redo) {
+            redo = 0;
+            op_Gx(q, x0, gx);
+            continue;
+        }
+        if (rc == 0 || rejected) break;
         op_Gx(q, x0, gx); /* d of the new candidates is measured at x0 */
     }
 out:

@@ -65,7 +65,11 @@
 #define PL_NC 256    // polish: candidate rows
 #define PL_PMAX 160  // polish: rows simultaneously active in the dual solve (wide batches; 112 on the wave path, whose
                      // workgroups are meant to share a CU's LDS in pairs)
+#define PL_PBIG 192  // second attempt of a polish whose dual solve ran out of capacity: factor in global memory (rare: ~1 batch QP in 800)
 __host__ __device__ inline int polish_pmax(int nk) { return nk <= 36 ? 112 : PL_PMAX; }
+__host__ __device__ inline size_t polish_ws_doubles(int nj, int nk) {  // cand, V, S, counters, big factor
+    return PL_NC * 14 + (size_t)(PL_NC + 1) * nj * nk + PL_NC * PL_NC + 8 + PL_PBIG * (PL_PBIG + 1) / 2;
+}
 __host__ __device__ inline int polish_lds_doubles(int nk) {
     const int pm = polish_pmax(nk);
     return pm * (pm + 1) / 2 + 3 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
@@ -139,7 +143,7 @@ __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
                (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 3) + 1) / 2 + 2 +
-               /* polish: cand, V, S, counters */ (PL_NC * 14 + (size_t)(PL_NC + 1) * d.nj * d.nk + PL_NC * PL_NC + 8) +
+               /* polish: cand, V, S, counters, big factor */ polish_ws_doubles(d.nj, d.nk) +
                /* row constants */ 4 * (size_t)nbmax * N * d.oq;
     return n;
 }
@@ -175,7 +179,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.fbase = w.fcnt + (size_t)nbmax * d.M;
     w.fperm = w.fbase + (size_t)nbmax * d.M;
     w.polish = p + ((size_t)nbmax * d.M * (d.N + 3) + 1) / 2 + 2;
-    w.rn0 = w.polish + (PL_NC * 14 + (size_t)(PL_NC + 1) * dm.nj * dm.nk + PL_NC * PL_NC + 8);
+    w.rn0 = w.polish + polish_ws_doubles(dm.nj, dm.nk);
     w.rn1 = w.rn0 + (size_t)nbmax * d.N * d.oq;
     w.rn2 = w.rn1 + (size_t)nbmax * d.N * d.oq;
     w.rhc = w.rn2 + (size_t)nbmax * d.N * d.oq;
@@ -1950,6 +1954,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     pw.V = w.polish + PL_NC * 14;
     pw.Sg = pw.V + (size_t)(PL_NC + 1) * d.nj * d.nk;
     pw.ncand = (int*)(pw.Sg + PL_NC * PL_NC);
+    pw.Lbig = pw.Sg + PL_NC * PL_NC + 8;
     row_pass<PASS_INIT>(c, io);
     __threadfence_block();
     __syncthreads();
@@ -2002,7 +2007,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
                            mu < (early_tries == 0 ? QP_EARLY_TOL : 1e-2 * QP_EARLY_TOL);
         if (S.p.polish && (polish_first || early)) {
             if (!polish_first) early_tries++;
-            const int acc = polish_entry(c, pw, lds, red2, flag2, polish_first);
+            const int acc = polish_entry(c, pw, lds, red2, flag2, polish_first ? 1 : 0);
             __syncthreads();
             PROF(0);
 #ifdef QP_POLSTATS
@@ -2113,7 +2118,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     // ---- active-set polish
     if (S.p.polish && !polished) {
-        const int acc = polish_entry(c, pw, lds, red2, flag2, false);
+        int acc = polish_entry(c, pw, lds, red2, flag2, 0);
+        if (acc == 3) {  // the dual active-set solve ran out of capacity: once more with the big factor in global memory
+            __syncthreads();
+            acc = polish_entry(c, pw, lds, red2, flag2, 2);
+        }
         polished = acc == 0 ? 1 : 0;
         PROF(0);
 #ifndef QP_PROFILE

@@ -1,0 +1,181 @@
+"""The timed workload, checked: the reference's 50-map sweep of the 64-agent mission (swarm_traj_planner_rbp_test_all.cpp:49-103,
+plan_rbp_test.launch keys) through ONE ragged device session -- every map with its own M = makespan + 2 -- against the
+CPU oracle map by map, plus BASELINE.json config C5 (batch_size 8, 50 Gauss-Seidel passes) and the batch_iter == 0 shortcut
+(rbp_planner.hpp:119-138).  Needs an MI355X; the oracle legs run on the host cores in a process pool.
+"""
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CTRL_TOL = 2e-6   # metres, sup norm (tests/test_gpu_parity.py)
+FEAS_TOL = 1e-8   # inequality rows [m]
+EQ_TOL = 5e-8     # rows of Aeq_base carry factors up to n(n-1)/dt^2 = 20: a control point snapped onto an active SFC face by <= 5e-9 m
+                  # (the polish's feasibility acceptance) shows up 4 x 20 times larger; CPLEX's default feasibility tolerance is 1e-6
+N_MAPS = 50
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _oracle_map(args):
+    """worker: distance grid, ECBS initial trajectory and the oracle's Corridor + RBPPlanner for one map"""
+    mid, n_agents, pkw = args
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission(f"mission_{n_agents}agents_15.json")
+    w = host.load_world(f"map{mid}.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref = init.clone_inputs()
+    rc1, ns = O.corridor_update(w, m, p, ref)
+    rc2, rep = O.planner_update(m, p, ref)
+    return dict(mid=mid, rc=(rc1, rc2), init_traj=init.init_traj, T0=init.T.copy(), ns=ns, sfc_count=ref.sfc_count, sfc_box=ref.sfc_box,
+                sfc_time=ref.sfc_time, rsfc_normal=ref.rsfc_normal, ctrl=ref.ctrl, coef=ref.coef, T=ref.T, time_scale=ref.time_scale,
+                total_cost=ref.total_cost, n_qp=rep["n_qp"], n_polished=rep["n_polished"])
+
+
+def oracle_sweep(map_ids, n_agents, pkw):
+    workers = max(1, min(len(map_ids), (os.cpu_count() or 2) - 1, 48))
+    with ProcessPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(_oracle_map, [(mid, n_agents, pkw) for mid in map_ids]))
+
+
+def test_all_50_maps_64_agents_vs_oracle():
+    """the headline workload (C3): every map of the sweep, 64 agents, batch_size 4, one session, no padding"""
+    from swarm_simulator_amd.types import PlanResult
+    pkw = {}
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission("mission_64agents_15.json")
+    refs = oracle_sweep(list(range(1, N_MAPS + 1)), 64, pkw)
+    assert all(r["rc"] == (0, 0) for r in refs)
+    worlds = [host.load_world(f"map{r['mid']}.bt", p) for r in refs]
+    plans = [PlanResult(r["init_traj"], r["T0"]) for r in refs]
+    Ms = sorted({pl.M for pl in plans})
+    assert len(Ms) > 1, "the sweep has maps with different makespans: the session must be ragged"
+    sess = planner.Session(worlds, [m] * N_MAPS, p, plans)
+    sess.run()
+    assert sess.download() == [0] * N_MAPS
+    ct = sess.counters()
+    worst, unpolished, oracle_loose = 0.0, [], []
+    for idx, (r, g) in enumerate(zip(refs, plans)):
+        tag = f"map{r['mid']} (M={g.M})"
+        # corridor: bit exact, same getDistance count
+        assert np.array_equal(r["sfc_count"], g.sfc_count), tag
+        assert np.array_equal(r["sfc_box"], g.sfc_box), tag
+        assert np.array_equal(bits(r["rsfc_normal"]), bits(g.rsfc_normal)), tag
+        # planner
+        err = float(np.abs(r["ctrl"] - g.ctrl).max())
+        if r["n_polished"] == r["n_qp"]:  # the oracle's answer is a certified optimum of every batch QP
+            worst = max(worst, err)
+            assert err < CTRL_TOL, f"{tag}: ctrl sup-err {err:.3e} (qp_unpolished={g.qp_unpolished}, kkt_max={g.kkt_max:.2e})"
+            assert abs(r["total_cost"] - g.total_cost) <= 1e-8 * max(1.0, abs(r["total_cost"])), tag
+        else:  # the ORACLE kept an interior-point answer for some batch (its own polish was refused): it is only good to ~1e-4 m
+            # there, so this map's GPU answer is judged by the independent numpy certificate below instead
+            oracle_loose.append(idx)
+            assert err < 1e-2, tag
+        assert r["time_scale"] == g.time_scale and np.array_equal(r["T"], g.T), tag
+        assert np.array_equal(r["sfc_time"], g.sfc_time), tag   # rescaled by the same time_scale (rbp_planner.hpp:250-252)
+        assert g.qp_solves == 16 and r["n_qp"] == 16, tag
+        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL, tag
+        if g.qp_unpolished:
+            unpolished.append((r["mid"], g.qp_unpolished, g.kkt_max, err))
+        else:
+            assert g.kkt_max < 1e-8, tag
+    assert int(ct["sfc_samples"]) == sum(r["ns"] for r in refs)
+    print(f"\n50-map sweep: worst ctrl sup-err {worst:.3e} m; maps with unpolished batch QPs (still within {CTRL_TOL} m): {unpolished}")
+    # every batch QP of the sweep must be a certified optimum -- or, where the polish was refused, the interior-point answer
+    # is flagged in rbp_plan (qp_unpolished, kkt_max) AND still meets the tolerance (asserted above)
+    assert ct["qp_solves"] == 16 * N_MAPS and ct["qp_polished"] == ct["qp_solves"] - sum(u[1] for u in unpolished)
+    sess.close()
+    # independent certificate (numpy restatement, tests/golden/make_kkt_reference.py): three batch QPs on three maps, and EVERY
+    # batch QP of the maps on which the oracle itself is not a certified optimum
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_kkt_reference as K
+    print(f"maps judged by the numpy certificate alone (oracle polish refused): {[refs[i]['mid'] for i in oracle_loose]}")
+    assert len(oracle_loose) <= 5
+    for idx, batches in [(0, [0]), (17, [7]), (42, [15])] + [(i, None) for i in oracle_loose]:
+        r, g = refs[idx], plans[idx]
+        # corridor times before timeScale: recomputed by the oracle's corridor (bit-identical to the GPU's, asserted above)
+        pr0 = PlanResult(r["init_traj"], r["T0"])
+        assert O.corridor_update(worlds[idx], m, p, pr0)[0] == 0
+        for rep in K.certify_plan(r["T0"], r["init_traj"], m.start, m.goal, m.radius, g.sfc_box, pr0.sfc_time, g.sfc_count, g.rsfc_normal,
+                                  pr0.rsfc_time, g.ctrl, p.sequential, p.batch_size, p.batch_iter, only_batches=batches):
+            tag = f"map{r['mid']} batch {rep['batch']}: " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
+            assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
+            assert rep["forward_error"] < CTRL_TOL, tag
+
+
+def test_c5_batch8_50_passes_vs_oracle():
+    """BASELINE.json C5 as specified: plan/sequential=true, batch_size=8, iteration=50 -- 16 agents against the oracle"""
+    pkw = dict(batch_size=8, iteration=50)
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission("mission_16agents_15.json")
+    r = _oracle_map((3, 16, pkw))
+    assert r["rc"] == (0, 0) and r["n_qp"] == 100
+    from swarm_simulator_amd.types import PlanResult
+    g = PlanResult(r["init_traj"], r["T0"])
+    w = host.load_world("map3.bt", p)
+    assert planner.Corridor(w, m, p).update(False, g)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, g), pl.last_error
+    assert g.qp_solves == 100
+    assert np.abs(r["ctrl"] - g.ctrl).max() < CTRL_TOL
+    assert abs(r["total_cost"] - g.total_cost) <= 1e-8 * max(1.0, abs(r["total_cost"]))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
+def test_c5_64_agents_properties():
+    """C5 on the 64-agent mission (400 batch QPs per mission): feasible under the reference's constraint sets, and the total
+    cost does not increase with the number of Gauss-Seidel passes (every batch QP minimises its agents' cost with the others
+    frozen, so the sum over agents is monotone)"""
+    m = host.load_mission("mission_64agents_15.json")
+    costs = []
+    for it in (1, 2, 50):
+        p = Param.test_sweep(batch_size=8, iteration=it)
+        w = host.load_world("map1.bt", p)
+        g = host.ecbs_plan(w, m, p)
+        assert planner.Corridor(w, m, p).update(False, g)
+        pl = planner.RBPPlanner(m, p)
+        assert pl.update(False, g), pl.last_error
+        assert g.qp_solves == 8 * it
+        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+        assert abs(obj - g.total_cost) <= 1e-8 * max(1.0, obj)
+        ratio, _ = host.validate(m, p, g)
+        assert ratio >= 1.0
+        costs.append(g.total_cost)
+    assert costs[0] >= costs[1] - 1e-9 and costs[1] >= costs[2] - 1e-9, costs
+    assert costs[2] < costs[0]
+
+
+def test_batch_iter_zero_publishes_initial_trajectory():
+    """plan/sequential=true with batch_iter == 0 (the ABI default of rbp_param_defaults is sequential=false, batch_iter=0;
+    with sequential=true it is the shortcut of rbp_planner.hpp:119-138): no QP is solved, the coefficients are those of `dummy`"""
+    p = Param.test_sweep(batch_iter=0)
+    m = host.load_mission("mission_8agents_15.json")
+    w = host.load_world("map5.bt", p)
+    g = host.ecbs_plan(w, m, p)
+    ref = g.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    assert O.planner_update(m, p, ref)[0] == 0
+    assert planner.Corridor(w, m, p).update(False, g)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, g), pl.last_error
+    assert g.qp_solves == 0 and g.qp_iterations == 0
+    dummy = O.build_dummy(g.init_traj)
+    assert np.array_equal(g.ctrl, dummy)
+    assert g.time_scale == ref.time_scale
+    assert np.abs(g.coef - ref.coef).max() < 1e-12 * max(1.0, np.abs(ref.coef).max())
+    # coefficient of (t - T_m)^0 is the first control point of the segment = waypoint m
+    assert np.allclose(g.coef[:, :, 5::6], np.transpose(g.init_traj[:, :-1, :].astype(np.float64), (0, 2, 1)), atol=1e-12)

@@ -1,0 +1,88 @@
+"""The oracle and the GPU are both certified by an INDEPENDENT numpy restatement of the reference's batch QP.
+
+tests/golden/make_kkt_reference.py restates populatebyrow (rbp_planner.hpp:551-688 with :327-549) as explicit matrices in the
+reference's variable order, takes nothing but the ACTIVE SET from a solver's answer, re-derives the optimum of the
+equality-constrained QP on that active set by dense float64 linear algebra (null-space method, SVD rank decisions) and proves
+it optimal for the full QP (all rows feasible, non-negative multipliers by NNLS).  The distance of a solver's answer from
+that point is its true forward error.  Neither oracle/planner.c nor the HIP kernel shares code or algorithm with it.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_kkt_reference as K  # noqa: E402
+
+from tests.common import Case  # noqa: E402
+
+FWD_TOL = 2e-6      # same tolerance as CTRL_TOL of the parity tests [m]
+FEAS_TOL = 1e-7     # rows of x_as [m] (CPLEX's default feasibility tolerance is 1e-6)
+STAT_TOL = 1e-7     # |reduced gradient + G_A' lambda|_inf / |2 |Q| |x||_inf  with lambda >= 0
+
+
+def certify_case(c, ctrl, only_batches=None):
+    g, m, p = c.g, c.mission, c.param
+    return K.certify_plan(g["T0"], g["init_traj"], m.start, m.goal, m.radius, g["sfc_box"], g["sfc_time0"], g["sfc_count"],
+                          g["rsfc_normal"], g["rsfc_time0"], ctrl, p.sequential, p.batch_size, p.batch_iter, only_batches=only_batches)
+
+
+def check_reports(reps, fwd_tol=FWD_TOL):
+    for r in reps:
+        tag = f"batch {r['batch']}: " + ", ".join(f"{k}={v:.3g}" for k, v in r.items() if isinstance(v, float))
+        assert r["viol_eq"] < 1e-8 and r["viol_ineq"] < FEAS_TOL, tag            # the solver's answer is feasible
+        assert r["x_as_viol_eq"] < 1e-8 and r["x_as_viol_ineq"] < FEAS_TOL, tag  # the re-derived point is feasible on ALL rows
+        assert r["stationarity"] < STAT_TOL, tag                                 # and has non-negative multipliers: it is the optimum
+        assert r["forward_error"] < fwd_tol, tag                                 # the solver's distance from it
+        assert r["objective"] >= r["objective_as"] - 1e-9 * max(1.0, abs(r["objective_as"])), tag
+
+
+def test_restated_matrices_match_the_oracle_restatement():
+    """two pens, one reference: Q_base, Aeq_base, dummy of the numpy restatement == those of oracle/planner.c"""
+    from tests import oracle_lib as O
+    Q, _ = O.Q_base()
+    assert np.array_equal(Q, K.Q_base())
+    T = np.array([0, 1.0, 2.5, 3.0, 4.2])
+    assert np.abs(O.Aeq_base(T) - K.Aeq_base(T)).max() < 1e-12
+    tr = np.random.default_rng(3).normal(size=(3, 5, 3)).astype(np.float32)
+    assert np.array_equal(O.build_dummy(tr).transpose(0, 2, 1), K.build_dummy(tr))
+
+
+@pytest.mark.parametrize("name", ["c1_4agents_empty_joint", "c1_4agents_empty_seq2", "s4_map1_joint", "s4_map1_seq2", "s8_map5_seq4"])
+def test_oracle_goldens_are_certified_optima(name):
+    """the committed golden control points (oracle output) pass the independent certificate, and the QP sizes agree"""
+    c = Case(name)
+    reps = certify_case(c, c.g["ctrl"])
+    assert len(reps) >= 1
+    check_reports(reps)
+    last = reps[-1]
+    assert [last["count_x"], last["count_eq"], last["count_lq"]] == c.g["sizes"].tolist()   # count_x / count_eq / count_lq :58-60
+
+
+def test_certificate_rejects_a_wrong_answer():
+    """sanity of the checker itself: a perturbed answer is flagged"""
+    c = Case("s4_map1_seq2")
+    ctrl = c.g["ctrl"].copy()
+    ctrl[0, 0, 40] += 1e-3
+    reps = certify_case(c, ctrl, only_batches=[0])
+    r = reps[0]
+    assert r["viol_eq"] > 1e-6 or r["forward_error"] > 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["s8_map5_seq4", "c2_16agents_map3", "c3_64agents_map1"])
+def test_gpu_answers_are_certified_optima(name):
+    """Corridor + RBPPlanner on the GPU through the C ABI; every batch QP of the plan certified by the numpy restatement"""
+    from swarm_simulator_amd import planner
+    c = Case(name)
+    pr = c.inputs()
+    assert planner.Corridor(c.world, c.mission, c.param).update(False, pr)
+    assert planner.RBPPlanner(c.mission, c.param).update(False, pr)
+    g, m, p = c.g, c.mission, c.param
+    T0 = g["T0"]
+    sfc_time0 = pr.sfc_time / pr.time_scale if pr.time_scale != 1.0 else pr.sfc_time  # noqa: F841 (corridor times come from the golden below)
+    reps = K.certify_plan(T0, g["init_traj"], m.start, m.goal, m.radius, pr.sfc_box, g["sfc_time0"], pr.sfc_count, pr.rsfc_normal,
+                          g["rsfc_time0"], pr.ctrl, p.sequential, p.batch_size, p.batch_iter)
+    check_reports(reps)
+    assert pr.qp_unpolished == 0 and pr.kkt_max < 1e-8
