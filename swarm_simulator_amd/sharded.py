@@ -5,7 +5,7 @@ One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the G
 What shards, and what does not:
   * Corridor::update shards by agent.  SFC boxes are independent per agent (rbp_corridor.hpp:154), RSFC rows are
     independent per pair and only read the two agents' waypoints (:342-392).  Rank r computes the agents of its
-    contiguous slice and the pair rows (qi, qj) whose qi lies in the slice; ONE all-gather per array then gives every
+    contiguous slice and the pair rows (qi, qj) whose qi lies in the slice; ONE fused all-gather of a packed byte buffer then gives every
     rank the complete corridor, bit-identical to the unsharded call (the exchange moves bytes, never adds floats).
   * RBPPlanner::update in the reference schedule (sequential=true) is a Gauss-Seidel sweep: batch l is solved against
     the answers of batches < l (rbp_planner.hpp:140-203), so inside one mission it is serial by construction.  Every rank
@@ -35,41 +35,57 @@ def pair_offset(n_agents: int, qi: int) -> int:
     return qi * n_agents - qi * (qi + 1) // 2
 
 
-def _all_gather_ragged(dist, dev, local: np.ndarray, counts):
-    """all-gather of byte blocks of different lengths: pad to the longest, one all_gather, cut.  Bytes only: exact."""
-    import torch
-    world = len(counts)
-    maxb = max(max(counts), 1)
-    buf = np.zeros(maxb, dtype=np.uint8)
-    raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
-    assert raw.size == counts[dist.get_rank()]
-    buf[:raw.size] = raw
-    t = torch.from_numpy(buf).to(dev)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t)
-    return [o.cpu().numpy()[:counts[r]] for r, o in enumerate(outs)]
+def _shard_layout(n_agents: int, M: int, MB: int, slices):
+    """byte length of every rank's packed shard: [sfc_count | sfc_box | sfc_time | rsfc_normal rows of the agents it owns]"""
+    per_agent = 4 + MB * 6 * 8 + MB * 8
+    row = M * 3 * 4
+    offs = [(pair_offset(n_agents, sb), pair_offset(n_agents, se)) for sb, se in slices]
+    lens = [(se - sb) * per_agent + (o1 - o0) * row for (sb, se), (o0, o1) in zip(slices, offs)]
+    return per_agent, row, offs, lens
+
+
+def pack_shard(plan: PlanResult, n_agents: int, sl, off):
+    (b, e), (o0, o1) = sl, off
+    parts = [plan.sfc_count[b:e], plan.sfc_box[b:e], plan.sfc_time[b:e], plan.rsfc_normal[o0:o1]]
+    return np.concatenate([np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in parts])
+
+
+def unpack_shard(plan: PlanResult, buf: np.ndarray, sl, off):
+    (b, e), (o0, o1) = sl, off
+    pos = 0
+    for arr, lo, hi in ((plan.sfc_count, b, e), (plan.sfc_box, b, e), (plan.sfc_time, b, e), (plan.rsfc_normal, o0, o1)):
+        dst = arr[lo:hi]
+        n = dst.nbytes
+        dst.view(np.uint8).reshape(-1)[:] = buf[pos:pos + n]
+        pos += n
+    assert pos == buf.size
 
 
 def gather_corridor(dist, plan: PlanResult, n_agents: int, slices, dev="cpu"):
-    """exchange the shards written by rbp_corridor_update_range so that `plan` holds the whole corridor on every rank."""
-    rank = dist.get_rank()
+    """exchange the shards written by rbp_corridor_update_range so that `plan` holds the whole corridor on every rank: ONE fused
+    all-gather of a packed byte buffer (SFC counts, boxes, end times and the RSFC rows of the owned agents; shards padded to the
+    longest one).  Bytes only -- nothing is added, so -0.0 normals and every bit of the boxes survive."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
     M, MB = plan.M, plan.sfc_box.shape[1]
-    b, e = slices[rank]
-    # per-agent arrays: sfc_count [N] i32, sfc_box [N][MB][6] f64, sfc_time [N][MB] f64
-    for arr, per_agent in ((plan.sfc_count, 4), (plan.sfc_box, MB * 6 * 8), (plan.sfc_time, MB * 8)):
-        counts = [(se - sb) * per_agent for sb, se in slices]
-        parts = _all_gather_ragged(dist, dev, arr[b:e], counts)
-        flat = arr.view(np.uint8).reshape(-1)
-        for (sb, se), part in zip(slices, parts):
-            flat[sb * per_agent:se * per_agent] = part
-    # pair rows: rsfc_normal [npair][M][3] f32, rows of qi in [b, e) are contiguous
-    row = M * 3 * 4
-    offs = [(pair_offset(n_agents, sb), pair_offset(n_agents, se)) for sb, se in slices]
-    counts = [(o1 - o0) * row for o0, o1 in offs]
-    parts = _all_gather_ragged(dist, dev, plan.rsfc_normal[offs[rank][0]:offs[rank][1]], counts)
-    flat = plan.rsfc_normal.view(np.uint8).reshape(-1)
-    for (o0, o1), part in zip(offs, parts):
-        flat[o0 * row:o1 * row] = part
+    _, _, offs, lens = _shard_layout(n_agents, M, MB, slices)
+    maxb = max(max(lens), 1)
+    buf = np.zeros(maxb, dtype=np.uint8)
+    mine = pack_shard(plan, n_agents, slices[rank], offs[rank])
+    assert mine.size == lens[rank]
+    buf[:mine.size] = mine
+    t = torch.from_numpy(buf).to(dev)
+    out = torch.empty(world * maxb, dtype=torch.uint8, device=dev)
+    try:
+        dist.all_gather_into_tensor(out, t)          # one collective: RCCL over xGMI on the GPU box
+    except (RuntimeError, NotImplementedError):       # a backend without the flat form
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        out = torch.cat(outs)
+    host = out.cpu().numpy()
+    for r in range(world):
+        if r != rank:
+            unpack_shard(plan, host[r * maxb:r * maxb + lens[r]], slices[r], offs[r])
 
 
 class ShardedCorridor:

@@ -109,3 +109,21 @@ def test_two_rank_gloo_sharded_corridor(tmp_path):
     import json
     res = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(res) == 2 and all(r["same"] and not r["bad"] for r in res), res
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` outside a torchrun environment re-executes itself under torch.distributed.run with two ranks
+    (here: gloo, --dry-run = initialise, aggregate, plan nothing); n_gpus is what the process group actually saw"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run",
+                          "--missions-per-gpu", "3"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["agents_all_ranks"] == 2 * 3 * 64 and res["maps_rank0"] == [1, 2, 3]
+    # a single process asked for 2 GPUs but launched by hand with WORLD_SIZE=1 reports what it has
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                         capture_output=True, text=True, env=env1, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
