@@ -106,7 +106,9 @@ struct QpDims {
     int nk, nj, ld;     // block order 9*nb, knots M-1, padded leading dimension
     int ldb;            // leading dimension of the knot blocks in global memory: nk (wave path) or nk rounded up to 16 (tiled path)
     int first;          // first agent of the batch (batches are contiguous: qi / batch_size == l)
-    size_t nbnd, nfro, npr, nrows;
+    int ncol0;          // rows every control point of a batch agent has: 6 bound rows + (nb - 1) in-batch pair rows
+    int ntile;          // 64-lane tiles of control points: ceil(nb * oq / 64)
+    size_t nslot_max;   // capacity of the row arrays: ntile * 64 * (ncol0 + NF)
 };
 
 __host__ __device__ inline QpDims make_dims(int N, int M, int first, int nb) {
@@ -114,16 +116,30 @@ __host__ __device__ inline QpDims make_dims(int N, int M, int first, int nb) {
     d.N = N, d.M = M, d.oq = 6 * M, d.nb = nb, d.NF = N - nb, d.npb = nb * (nb - 1) / 2;
     d.nk = 9 * nb, d.nj = M - 1, d.ld = d.nk + 1, d.first = first;
     d.ldb = d.nk <= 36 ? d.nk : ((d.nk + 15) & ~15);
-    d.nbnd = (size_t)nb * 6 * d.oq, d.nfro = (size_t)nb * d.NF * d.oq, d.npr = (size_t)d.npb * d.oq;
-    d.nrows = d.nbnd + d.nfro + d.npr;
+    d.ncol0 = 6 + nb - 1, d.ntile = (nb * d.oq + 63) / 64;
+    d.nslot_max = (size_t)d.ntile * 64 * (d.ncol0 + d.NF);
     return d;
 }
 
-// workspace (doubles) per mission, sized for the largest batch
+// ROW STORAGE ("sliced ELLPACK", slice = one wavefront).  A sweep hands one control point (agent a, segment, i) of a batch agent
+// to a thread; that thread owns ALL rows that touch its control point:
+//     6 bound rows  |  nb - 1 in-batch pair rows  |  cnt(a, segment) frozen-neighbour rows that survived the presolve
+// Control points are numbered wi = 6 * rank(a, segment) + i with the (a, segment) groups ranked by falling row count, 64
+// consecutive wi form a tile (= the lanes of one wavefront), and row `idx` of control point wi lives in slot
+//     tile_base[wi / 64] + idx * 64 + (wi % 64)
+// so every load/store of a sweep is ONE coalesced 512-byte access per wavefront and array, and consecutive rows of a thread
+// are consecutive 512-byte lines: a pure stream.  (The previous layout kept the rows of a group contiguous: a wavefront then
+// touched eleven 48-byte pieces of different cache lines per array and step, and HBM-side traffic was ~2.5x the bytes used.)
+// A pair row is shared by two control points (one of each agent) and is STORED TWICE, once in each one's column: both copies
+// are updated by the same arithmetic on the same inputs, hence stay bit-identical; reductions count the copy of the lower
+// agent only.  Only (s, z) are stored per row -- the corrector term and the step (ds, dz) are recomputed where they are needed
+// (they are functions of s, z and the two direction vectors), which halves the bytes of a sweep; the step sweep writes the
+// new (s, z) into a second pair of arrays (ping-pong) so that a rejected step can be repeated from the old state.
 struct QpWs {
-    double *s, *z, *ds, *dz, *cc;   // row state [nrows]
-    double *cpacc;                  // [nb*oq][12]: S(6) yv(3) gz(3) per control point
-    double *pracc;                  // [npb*oq][12]
+    double *s, *z, *s2, *z2;        // row state [nslot]: current / next
+    double *rh;                     // [nslot] frozen-neighbour rows: the constant of slack = rh - n . x_a
+    double *cc, *ds;                // [nslot] polish only: candidate marks / slack at the trial point
+    double *cpacc;                  // [nb*oq][12]: S(6) yv(3) gz(3) per control point, ALL its rows (bounds, pairs, frozen)
     double *dx, *dxa, *cvec;        // [nb*3*oq]
     double *rbase, *rhs;            // [(M-1)*nk]
     double *Td, *To;                // [(M-1)][nk*nk], [(M-2)][nk*nk]
@@ -132,19 +148,26 @@ struct QpWs {
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
     int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
-    int* fperm;                     // [nb][M]: (agent, segment) groups ordered by falling row count (sweep work order)
+    int *fperm, *frank;             // [nb][M]: groups ordered by falling row count (fperm[rank] = group, frank[group] = rank)
+    int *tile_base;                 // [ntile + 1] first slot of each tile
+    int *wi_of;                     // [nb*oq] column (wi) of control point (a, j6)
+    float* nrm;                     // [sum cnt][3] signed normal of frozen row (group, idx): the six rows of a group share it
     double* polish;                 // PolishWs storage
-    double *rn0, *rn1, *rn2, *rhc;  // per frozen-neighbour row: signed normal and constant  (slack = rhc - rn . x_a)
 };
+
+__host__ __device__ inline size_t ws_int_count(int N, int M, int nbmax) {
+    QpDims d = make_dims(N, M, 0, nbmax);
+    return (size_t)nbmax * M * N /*flist*/ + 4 * (size_t)nbmax * M /*fcnt fbase fperm frank*/ + d.ntile + 1 + (size_t)nbmax * d.oq /*wi_of*/ +
+           3 * (size_t)nbmax * M * N /*nrm (floats)*/ + 8;
+}
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
-    size_t n = 5 * d.nrows + 12 * (size_t)nbmax * d.oq + 12 * (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
+    size_t n = 7 * d.nslot_max + 12 * (size_t)nbmax * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
                (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
-               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + ((size_t)nbmax * M * (N + 3) + 1) / 2 + 2 +
-               /* polish: cand, V, S, counters, big factor */ polish_ws_doubles(d.nj, d.nk) +
-               /* row constants */ 4 * (size_t)nbmax * N * d.oq;
+               2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + (ws_int_count(N, M, nbmax) + 1) / 2 + 2 +
+               /* polish: cand, V, S, counters, big factor */ polish_ws_doubles(d.nj, d.nk);
     return n;
 }
 
@@ -152,13 +175,14 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     QpDims dm = make_dims(d.N, d.M, 0, nbmax);
     QpWs w;
     double* p = base;
-    w.s = p, p += dm.nrows;
-    w.z = p, p += dm.nrows;
-    w.ds = p, p += dm.nrows;
-    w.dz = p, p += dm.nrows;
-    w.cc = p, p += dm.nrows;
+    w.s = p, p += dm.nslot_max;
+    w.z = p, p += dm.nslot_max;
+    w.s2 = p, p += dm.nslot_max;
+    w.z2 = p, p += dm.nslot_max;
+    w.rh = p, p += dm.nslot_max;
+    w.cc = p, p += dm.nslot_max;
+    w.ds = p, p += dm.nslot_max;
     w.cpacc = p, p += 12 * (size_t)nbmax * d.oq;
-    w.pracc = p, p += 12 * (size_t)(dm.npb ? dm.npb : 1) * d.oq;
     w.dx = p, p += (size_t)nbmax * 3 * d.oq;
     w.dxa = p, p += (size_t)nbmax * 3 * d.oq;
     w.cvec = p, p += (size_t)nbmax * 3 * d.oq;
@@ -174,15 +198,16 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.Dk = p, p += (size_t)(d.M + 1) * 9;
     w.Ek = p, p += (size_t)(d.M + 1) * 9;
     w.segsc = p, p += d.M;
-    w.flist = (int*)p;
-    w.fcnt = w.flist + (size_t)nbmax * d.M * d.N;
-    w.fbase = w.fcnt + (size_t)nbmax * d.M;
-    w.fperm = w.fbase + (size_t)nbmax * d.M;
-    w.polish = p + ((size_t)nbmax * d.M * (d.N + 3) + 1) / 2 + 2;
-    w.rn0 = w.polish + polish_ws_doubles(dm.nj, dm.nk);
-    w.rn1 = w.rn0 + (size_t)nbmax * d.N * d.oq;
-    w.rn2 = w.rn1 + (size_t)nbmax * d.N * d.oq;
-    w.rhc = w.rn2 + (size_t)nbmax * d.N * d.oq;
+    int* ip = (int*)p;
+    w.flist = ip, ip += (size_t)nbmax * d.M * d.N;
+    w.fcnt = ip, ip += (size_t)nbmax * d.M;
+    w.fbase = ip, ip += (size_t)nbmax * d.M;
+    w.fperm = ip, ip += (size_t)nbmax * d.M;
+    w.frank = ip, ip += (size_t)nbmax * d.M;
+    w.tile_base = ip, ip += dm.ntile + 1;
+    w.wi_of = ip, ip += (size_t)nbmax * d.oq;
+    w.nrm = (float*)ip;
+    w.polish = p + (ws_int_count(d.N, d.M, nbmax) + 1) / 2 + 2;
     return w;
 }
 
@@ -274,8 +299,8 @@ __device__ void mission_constants(const QpDims& d, const double* T, QpWs& w) {
 // only checked once (presolve).  Work item = one free control point of one batch agent (all its bound and frozen
 // rows), then one (pair, control point).
 // ------------------------------------------------------------------------------------------------------------
-enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_CORR_RHS, PASS_STEP, PASS_NBHD, PASS_UPDATE, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY, PASS_CAND_GEO,
-       PASS_UPBUILD /* UPDATE of iteration i fused with BUILD of iteration i+1: one read of the row state instead of two */ };
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_STEP, PASS_PRESOLVE, PASS_CAND, PASS_VERIFY, PASS_CAND_GEO,
+       PASS_UPBUILD /* step of iteration i (old state -> new state arrays) fused with BUILD of iteration i+1 */ };
 
 struct PassIO {
     // inputs
@@ -302,7 +327,7 @@ struct RowCtx {
 };
 
 // 1/x for the row arithmetic of the sweeps: v_rcp_f64 plus two Newton steps (relative error ~1e-16 for normal x > 0).
-// An IEEE division costs three times as many instructions (div_scale, div_fmas, div_fixup); the sweeps are issue-bound.
+// An IEEE division costs three times as many instructions (div_scale, div_fmas, div_fixup).
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -322,66 +347,74 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
+// One row of G x <= h at slot r.  slack = h - g.x at the CURRENT control points (PASS_UPBUILD: at the trial point x + alpha dx),
+// ga = g . dx_aff, gd = g . dx.  cw = 1 for rows that count in the sums, 0 for the second copy of a pair row.  Returns the
+// Newton weight wgt, the right-hand-side scalar v and the multiplier zo where the pass defines them.  Step-length limits are
+// tracked as io.vmax = max(-ds/s, -dz/z) (the caller takes the reciprocal), which needs no data-dependent division.
+// The corrector term cc = ds_aff dz_aff and the step (ds, dz) are functions of (s, z, ga, gd): the STEP and UPBUILD sweeps
+// recompute them instead of reading them back (three stored arrays fewer, see the note above QpWs).
 template <int PASS>
-__device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, size_t r, const QpWs& w, PassIO& io,
-                                       double& wgt, double& v) {
-    // slack = h - g.x ; returns weight wgt and rhs scalar v where relevant.  Step-length limits are tracked as
-    // io.vmax = max(-ds/s, -dz/z) (the caller takes the reciprocal), which needs no data-dependent division.
+__device__ __forceinline__ void row_op(double slack, double ga, double gd, size_t r, const QpWs& w, PassIO& io, double cw, double& wgt,
+                                       double& v, double& zo) {
     if (PASS == PASS_INIT) {
-        double s = slack < io.s_floor ? io.s_floor : slack;
+        const double s = slack < io.s_floor ? io.s_floor : slack;
         w.s[r] = s;
         w.z[r] = io.mu0 / s;
-    } else if (PASS == PASS_BUILD || PASS == PASS_UPBUILD) {
-        double s = w.s[r], z = w.z[r];
-        if (PASS == PASS_UPBUILD) {
-            s += io.alpha * w.ds[r], z += io.alpha * w.dz[r];
-            w.s[r] = s, w.z[r] = z;
-            io.vmin = fmin(io.vmin, s * z);  // wide-neighbourhood test of the step just applied
-        }
+    } else if (PASS == PASS_BUILD) {
+        const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
         wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
-        v = -wgt * (rg - s);  // predictor: rc / z = s
-        io.sum0 += s * z;
+        v = -wgt * (rg - s);                  // predictor: rc / z = s
+        zo = z;
+        io.sum0 += cw * s * z;
         io.vmax = fmax(io.vmax, fabs(rg));
     } else if (PASS == PASS_AFF) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
-        const double dza = wgt * (gdx_a + rg - s);
+        const double dza = wgt * (ga + rg - s);
         const double dsa = -s - s * dza * iz;  // (-s z - s dza) / z
         const double cc = dsa * dza;
-        w.cc[r] = cc;
         io.vmax = fmax(io.vmax, fmax(-dsa * is, -dza * iz));
-        io.sum0 += s * z, io.sum1 += s * dza + z * dsa, io.sum2 += cc;
+        io.sum0 += cw * s * z, io.sum1 += cw * (s * dza + z * dsa), io.sum2 += cw * cc;
         // the corrector's right-hand side is affine in sigma*mu, which is only known after this sweep's reductions:
         //   v_corr = -wgt (rg - (s z + cc - sigma mu) / z) = v - sigma mu * wgt / z.   Both parts are accumulated here, so
         // the corrector needs no sweep of its own (out: v, and wgt := wgt / z)
         v = -wgt * (rg - s - cc * iz);
         wgt = wgt * iz;
-    } else if (PASS == PASS_CORR_RHS) {
-        const double s = w.s[r], z = w.z[r];
-        const double rg = s - slack;
-        wgt = z * fast_rcp(s + io.dreg * z);
-        const double rcc = s * z + w.cc[r] - io.sigma_mu;
-        v = -wgt * (rg - rcc * fast_rcp(z));
     } else if (PASS == PASS_STEP) {
         const double s = w.s[r], z = w.z[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
-        const double rcc = s * z + w.cc[r] - io.sigma_mu;
-        const double dz = wgt * (gdx + rg - rcc * iz);
+        const double dza = wgt * (ga + rg - s);
+        const double cc = (-s - s * dza * iz) * dza;
+        const double rcc = s * z + cc - io.sigma_mu;
+        const double dz = wgt * (gd + rg - rcc * iz);
         const double ds = -(rcc + s * dz) * iz;
-        w.ds[r] = ds, w.dz[r] = dz;
         io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
-    } else if (PASS == PASS_NBHD) {
-        const double p = (w.s[r] + io.alpha * w.ds[r]) * (w.z[r] + io.alpha * w.dz[r]);
-        io.sum0 += p;
-        io.vmin = fmin(io.vmin, p);
-    } else if (PASS == PASS_UPDATE) {
-        w.s[r] += io.alpha * w.ds[r];
-        w.z[r] += io.alpha * w.dz[r];
+    } else if (PASS == PASS_UPBUILD) {
+        // old state (s, z) at the old point: slack_old = slack + alpha * gd
+        const double s = w.s[r], z = w.z[r];
+        const double rg = s - (slack + io.alpha * gd);
+        const double iz = fast_rcp(z);
+        const double w0 = z * fast_rcp(s + io.dreg * z);
+        const double dza = w0 * (ga + rg - s);
+        const double cc = (-s - s * dza * iz) * dza;
+        const double rcc = s * z + cc - io.sigma_mu;
+        const double dz = w0 * (gd + rg - rcc * iz);
+        const double ds = -(rcc + s * dz) * iz;
+        const double sn = s + io.alpha * ds, zn = z + io.alpha * dz;
+        w.s2[r] = sn, w.z2[r] = zn;
+        io.vmin = fmin(io.vmin, sn * zn);  // wide-neighbourhood test of the step just applied
+        // ... and the next iteration's weights / residuals at the new point
+        const double rgn = sn - slack;
+        wgt = zn * fast_rcp(sn + io.dreg * zn);
+        v = -wgt * (rgn - sn);
+        zo = zn;
+        io.sum0 += cw * sn * zn;
+        io.vmax = fmax(io.vmax, fabs(rgn));
     } else if (PASS == PASS_PRESOLVE) {
         io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
     } else if (PASS == PASS_CAND) {
@@ -397,7 +430,7 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
         w.cc[r] = wgt;
         v = slack;
     } else if (PASS == PASS_VERIFY) {
-        const double sn = slack - gdx;  // slack at x + dx
+        const double sn = slack - gd;  // slack at x + dx
         w.ds[r] = sn;
         io.vmax = fmax(io.vmax, -sn);
         if (sn < -1e-11 && w.cc[r] == 0.0) {  // violated row that is not a candidate yet
@@ -407,161 +440,144 @@ __device__ __forceinline__ void row_op(double slack, double gdx_a, double gdx, s
     }
 }
 
+// One sweep over all rows of the batch QP.  Rows (G x <= h form, as in the oracle):
+//   bound   (a,k,side,j6):  +x <= hi   /  -x <= -lo                       rbp_planner.hpp:626-635
+//   pair    (a<b,j6):       n . x_a - n . x_b <= -rr                      :668-679
+//   frozen  (a,f,j6):       sg * n . x_a <= -rr + sg * n . dummy_f        :645-666   sg = +1 if a < f else -1
+// Control points j6 < 3 and j6 >= 6M-3 are pinned by the end-state equalities: their rows are constants and are only checked
+// once (presolve).  Work item = one free control point of one batch agent with ALL its rows (see the note above QpWs).
 template <int PASS>
 __device__ void row_pass(const RowCtx& c, PassIO& io) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int oq = d.oq, N = d.N;
+    const int oq = d.oq, N = d.N, M = d.M, nb = d.nb;
     constexpr bool build = (PASS == PASS_BUILD || PASS == PASS_UPBUILD);
-    constexpr bool accum = (build || PASS == PASS_CORR_RHS || PASS == PASS_AFF);
     constexpr bool aff = (PASS == PASS_AFF);  // S[0..2] / S[3..5] then hold the two parts of the corrector rhs (see row_op)
+    constexpr bool accum = (build || aff);
     constexpr bool pinned_only = (PASS == PASS_PRESOLVE);
-    // ---- control points of batch agents: bound + frozen rows
-    const int ncp = d.nb * oq;
+    constexpr bool cand = (PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY);
+    constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
+    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_VERIFY || PASS == PASS_UPBUILD);
+    const int ncp = nb * oq;
     for (int wi = threadIdx.x; wi < ncp; wi += QP_THREADS) {
-        const int grp = w.fperm[wi / 6], a = grp / d.M, seg = grp % d.M, j6 = 6 * seg + wi % 6, it = a * oq + j6;
+        const int grp = w.fperm[wi / 6], a = grp / M, seg = grp - a * M, i = wi % 6, j6 = 6 * seg + i, it = a * oq + j6;
         const bool pinned = (j6 < 3 || j6 >= oq - 3);
         if (pinned != pinned_only) continue;
         const int qa = d.first + a;
+        const size_t base = (size_t)w.tile_base[wi >> 6] + (wi & 63);
         double xa[3], da[3], dd[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             xa[k] = c.ctrl[((size_t)qa * 3 + k) * oq + j6];
-            da[k] = (PASS == PASS_AFF) ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
-            dd[k] = (PASS == PASS_STEP || PASS == PASS_VERIFY) ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = need_dd ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
-        // bounds
+        // ---- bound rows (idx 0..5)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double hi = w.boxhi[((size_t)a * d.M + seg) * 3 + k], lo = w.boxlo[((size_t)a * d.M + seg) * 3 + k];
+            const double hi = w.boxhi[((size_t)a * M + seg) * 3 + k], lo = w.boxlo[((size_t)a * M + seg) * 3 + k];
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
-                const size_t r = ((size_t)(a * 3 + k) * 2 + side) * oq + j6;
+                const size_t r = base + (size_t)(2 * k + side) * 64;
                 const double sg = side == 0 ? 1.0 : -1.0;
                 const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
-                double wgt = 0, v = 0;
-                row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, wgt, v);
-                if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0)
+                double wgt = 0, v = 0, zo = 0;
+                row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, 1.0, wgt, v, zo);
+                if (cand && wgt != 0)
                     emit_cand(d, w, *c.pw, r, j6, a, -1, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack,
                               (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo, wgt);
                 if (accum) {
                     const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);  // diagonal slots of the packed 3x3
                     if (build) {
                         S[dg] += wgt;
-                        gz[k] += sg * w.z[r];
-                    }
-                    if (aff)
-                        S[k] += sg * v, S[3 + k] += sg * wgt;
-                    else
+                        gz[k] += sg * zo;
                         yv[k] += sg * v;
+                    } else {
+                        S[k] += sg * v, S[3 + k] += sg * wgt;
+                    }
                 }
             }
         }
-        // frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped).
-        // Row constants (signed normal, rhs) were tabulated once per QP: the sweep is a pure stream over SoA arrays.
-        const int cnt = w.fcnt[a * d.M + seg];
-        const size_t rbase = d.nbnd + (size_t)w.fbase[a * d.M + seg] * 6 + (j6 - 6 * seg);
-#pragma unroll 2
+        // ---- in-batch pair rows (idx 6 .. 6 + nb - 2): canonical orientation n . (x_hi - x_lo) >= rr, so that the copy in the
+        // other agent's column sees bit-identical inputs
+        for (int pb = 0; pb < nb - 1; ++pb) {
+            const int b = pb < a ? pb : pb + 1;
+            const bool a_lo = a < b;
+            const int qb = d.first + b;
+            const size_t r = base + (size_t)(6 + pb) * 64;
+            const float* nv = c.normals + (pair_index(N, a_lo ? qa : qb, a_lo ? qb : qa) * M + seg) * 3;
+            const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
+            double xb[3], gab = 0, gdb = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xb[k] = c.ctrl[((size_t)qb * 3 + k) * oq + j6];
+            // e = x_hi - x_lo ; the G row is  n . x_lo - n . x_hi <= -rr
+            const double e0 = a_lo ? xb[0] - xa[0] : xa[0] - xb[0], e1 = a_lo ? xb[1] - xa[1] : xa[1] - xb[1],
+                         e2 = a_lo ? xb[2] - xa[2] : xa[2] - xb[2];
+            const double slack = n0 * e0 + n1 * e1 + n2 * e2 - (c.radius[qa] + c.radius[qb]);
+            if (need_da) {
+                const double f0 = w.dxa[((size_t)b * 3 + 0) * oq + j6], f1 = w.dxa[((size_t)b * 3 + 1) * oq + j6],
+                             f2 = w.dxa[((size_t)b * 3 + 2) * oq + j6];
+                gab = a_lo ? n0 * (da[0] - f0) + n1 * (da[1] - f1) + n2 * (da[2] - f2) : n0 * (f0 - da[0]) + n1 * (f1 - da[1]) + n2 * (f2 - da[2]);
+            }
+            if (need_dd) {
+                const double f0 = w.dx[((size_t)b * 3 + 0) * oq + j6], f1 = w.dx[((size_t)b * 3 + 1) * oq + j6],
+                             f2 = w.dx[((size_t)b * 3 + 2) * oq + j6];
+                gdb = a_lo ? n0 * (dd[0] - f0) + n1 * (dd[1] - f1) + n2 * (dd[2] - f2) : n0 * (f0 - dd[0]) + n1 * (f1 - dd[1]) + n2 * (f2 - dd[2]);
+            }
+            double wgt = 0, v = 0, zo = 0;
+            row_op<PASS>(slack, gab, gdb, r, w, io, a_lo ? 1.0 : 0.0, wgt, v, zo);
+            if (cand && wgt != 0 && a_lo) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
+            if (accum) {
+                const double sg = a_lo ? 1.0 : -1.0;  // coefficient of x_a in the row is sg * n
+                if (build) {
+                    S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
+                    S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
+                    const double zz = sg * zo, vv = sg * v;
+                    gz[0] += zz * n0, gz[1] += zz * n1, gz[2] += zz * n2;
+                    yv[0] += vv * n0, yv[1] += vv * n1, yv[2] += vv * n2;
+                } else {
+                    const double vv = sg * v, ww = sg * wgt;
+                    S[0] += vv * n0, S[1] += vv * n1, S[2] += vv * n2;
+                    S[3] += ww * n0, S[4] += ww * n1, S[5] += ww * n2;
+                }
+            }
+        }
+        // ---- frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped): a stream
+        // over the SELL arrays; the signed normal is shared by the six rows of the group
+        const int cnt = w.fcnt[grp];
+        const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
+        const size_t r0 = base + (size_t)d.ncol0 * 64;
+#pragma unroll 4
         for (int idx = 0; idx < cnt; ++idx) {
-            const size_t r = rbase + (size_t)idx * 6;
-            const size_t fr = r - d.nbnd;
-            const double n0 = w.rn0[fr], n1 = w.rn1[fr], n2 = w.rn2[fr];
-            const double slack = w.rhc[fr] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
-            double wgt = 0, v = 0;
-            row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, wgt, v);
-            if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
+            const size_t r = r0 + (size_t)idx * 64;
+            const double n0 = nr[3 * idx], n1 = nr[3 * idx + 1], n2 = nr[3 * idx + 2];
+            const double slack = w.rh[r] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
+            double wgt = 0, v = 0, zo = 0;
+            row_op<PASS>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, 1.0, wgt, v, zo);
+            if (cand && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
             if (accum) {
                 if (build) {
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
                     S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
-                    const double z = w.z[r];
-                    gz[0] += z * n0, gz[1] += z * n1, gz[2] += z * n2;
-                }
-                if (aff) {
+                    gz[0] += zo * n0, gz[1] += zo * n1, gz[2] += zo * n2;
+                    yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+                } else {
                     S[0] += v * n0, S[1] += v * n1, S[2] += v * n2;
                     S[3] += wgt * n0, S[4] += wgt * n1, S[5] += wgt * n2;
-                } else {
-                    yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
                 }
             }
         }
         if (accum) {
             double* acc = w.cpacc + (size_t)it * 12;
-            if (build || aff) {
 #pragma unroll
-                for (int e = 0; e < 6; ++e) acc[e] = S[e];
-            }
+            for (int e = 0; e < 6; ++e) acc[e] = S[e];
             if (build) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) acc[9 + e] = gz[e];
-            }
-            if (!aff) {
-#pragma unroll
-                for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e];
+                for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e], acc[9 + e] = gz[e];
             }
         }
     }
-#ifdef QP_SWEEPSTATS
-    long long sw_t0 = 0;
-    if (PASS == PASS_STEP) {
-        __syncthreads();
-        sw_t0 = wall_clock64();
-    }
-#endif
-    // ---- in-batch pairs
-    const int npi = d.npb * oq;
-    for (int it = threadIdx.x; it < npi; it += QP_THREADS) {
-        const int pr = it / oq, j6 = it % oq, seg = j6 / 6;
-        const bool pinned = (j6 < 3 || j6 >= oq - 3);
-        if (pinned != pinned_only) continue;
-        int a = 0, rem = pr;
-        while (rem >= d.nb - 1 - a) rem -= d.nb - 1 - a, a++;
-        const int b = a + 1 + rem;
-        const int qa = d.first + a, qb = d.first + b;
-        const size_t r = d.nbnd + d.nfro + (size_t)pr * oq + j6;
-        const float* nv = c.normals + (pair_index(N, qa, qb) * d.M + seg) * 3;
-        const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
-        double e0 = c.ctrl[((size_t)qb * 3 + 0) * oq + j6] - c.ctrl[((size_t)qa * 3 + 0) * oq + j6];
-        double e1 = c.ctrl[((size_t)qb * 3 + 1) * oq + j6] - c.ctrl[((size_t)qa * 3 + 1) * oq + j6];
-        double e2 = c.ctrl[((size_t)qb * 3 + 2) * oq + j6] - c.ctrl[((size_t)qa * 3 + 2) * oq + j6];
-        const double slack = n0 * e0 + n1 * e1 + n2 * e2 - (c.radius[qa] + c.radius[qb]);
-        double ga = 0, gd = 0;
-        if (PASS == PASS_AFF) {
-            ga = n0 * (w.dxa[((size_t)a * 3 + 0) * oq + j6] - w.dxa[((size_t)b * 3 + 0) * oq + j6]) +
-                 n1 * (w.dxa[((size_t)a * 3 + 1) * oq + j6] - w.dxa[((size_t)b * 3 + 1) * oq + j6]) +
-                 n2 * (w.dxa[((size_t)a * 3 + 2) * oq + j6] - w.dxa[((size_t)b * 3 + 2) * oq + j6]);
-        }
-        if (PASS == PASS_STEP || PASS == PASS_VERIFY) {
-            gd = n0 * (w.dx[((size_t)a * 3 + 0) * oq + j6] - w.dx[((size_t)b * 3 + 0) * oq + j6]) +
-                 n1 * (w.dx[((size_t)a * 3 + 1) * oq + j6] - w.dx[((size_t)b * 3 + 1) * oq + j6]) +
-                 n2 * (w.dx[((size_t)a * 3 + 2) * oq + j6] - w.dx[((size_t)b * 3 + 2) * oq + j6]);
-        }
-        double wgt = 0, v = 0;
-        row_op<PASS>(slack, ga, gd, r, w, io, wgt, v);
-        if ((PASS == PASS_CAND || PASS == PASS_CAND_GEO || PASS == PASS_VERIFY) && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
-        if (accum) {
-            double* acc = w.pracc + (size_t)it * 12;
-            if (build) {
-                acc[0] = wgt * n0 * n0, acc[1] = wgt * n0 * n1, acc[2] = wgt * n0 * n2;
-                acc[3] = wgt * n1 * n1, acc[4] = wgt * n1 * n2, acc[5] = wgt * n2 * n2;
-                const double z = w.z[r];
-                acc[9] = z * n0, acc[10] = z * n1, acc[11] = z * n2;
-            }
-            if (aff) {
-                acc[0] = v * n0, acc[1] = v * n1, acc[2] = v * n2;
-                acc[3] = wgt * n0, acc[4] = wgt * n1, acc[5] = wgt * n2;
-            } else {
-                acc[6] = v * n0, acc[7] = v * n1, acc[8] = v * n2;
-            }
-        }
-    }
-#ifdef QP_SWEEPSTATS
-    if (PASS == PASS_STEP) {
-        __syncthreads();
-        if (threadIdx.x == 0) c.scal[23] += (double)(wall_clock64() - sw_t0);
-    }
-#endif
 }
 
 // A sweep of the interior-point loop.  In the 256-VGPR build it is a stand-alone function (own register allocation,
@@ -630,13 +646,7 @@ __device__ void rbase_from_acc(const RowCtx& c, double& dmax, double& gmax) {
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) gv += c_Qbase[6 * i + jj] * xs[jj];
             gv *= 2 * w.segsc[m];
-            gv += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];
-            for (int o = 0; o < d.nb; ++o) {  // pairs (a,o): row = n.x_lo - n.x_hi
-                if (o == a) continue;
-                const int lo = a < o ? a : o, hi = a < o ? o : a;
-                const double v = w.pracc[((size_t)(lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12 + 9 + k];
-                gv += (a == lo) ? v : -v;
-            }
+            gv += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];  // G'z of ALL rows of this control point (bounds, pairs, frozen)
             g[q] = -gv;
             gmax = fmax(gmax, fabs(gv));
         }
@@ -663,14 +673,7 @@ __device__ void rhs_from_acc(const RowCtx& c, bool corrector, double sigma_mu) {
         for (int q = 0; q < 6; ++q) {
             const int j6 = 6 * (j - 1) + 3 + q;
             const double* ac = w.cpacc + ((size_t)a * oq + j6) * 12;
-            double gv = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
-            for (int o = 0; o < d.nb; ++o) {
-                if (o == a) continue;
-                const int lo = a < o ? a : o, hi = a < o ? o : a;
-                const double* ap = w.pracc + ((size_t)(lo * d.nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12;
-                const double v = corrector ? ap[k] - sigma_mu * ap[3 + k] : ap[6 + k];
-                gv += (a == lo) ? v : -v;
-            }
+            const double gv = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
             g[q] = gv;
         }
         const double* L = w.Lk + 9 * j;
@@ -688,27 +691,20 @@ __device__ inline double sym3(const double* S, int k, int l) {
     return S[a == 0 ? b : (a == 1 ? 2 + b : 5)];
 }
 
-__device__ void assemble_blocks(const RowCtx& c, double* lds) {
+__device__ void assemble_blocks(const RowCtx& c, double* lds, double dreg) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
-    // stage 1: per (agent, control point) the 3x3 weight sum of ALL its rows (own bounds + frozen neighbours from the
-    // sweep, plus the in-batch pairs it takes part in), parked in LDS when it fits
+    const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb, M = d.M, N = d.N;
+    // stage 1: per (agent, control point) the 3x3 weight sum of ALL its rows (bounds, in-batch pairs, frozen neighbours) as the
+    // sweep left it in cpacc, parked in LDS when it fits (every entry is read by nine (k, l) work items)
     const bool in_lds = nb * oq * 6 <= c.lds_avail;
     if (in_lds) {
-        for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) {
-            const int e = it % 6, j6 = (it / 6) % oq, a = it / (6 * oq);
-            double sv = w.cpacc[((size_t)a * oq + j6) * 12 + e];
-            for (int o = 0; o < nb; ++o) {
-                if (o == a) continue;
-                const int lo = a < o ? a : o, hi = a < o ? o : a;
-                sv += w.pracc[((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12 + e];
-            }
-            lds[it] = sv;
-        }
+        for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) lds[it] = w.cpacc[(size_t)(it / 6) * 12 + it % 6];
         __syncthreads();
     }
-    // stage 2: work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out
+    // stage 2: work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out.
+    // Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight is recomputed from the row's (s, z) in the
+    // column of the lower agent (16 bytes per row instead of a stored 3x3)
     const int per_knot = nb * nb * 9;
     for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
         const int j = it / per_knot + 1, r = it % per_knot;
@@ -719,20 +715,14 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds) {
             const int j6 = 6 * (j - 1) + 3 + p;
             double sv;
             if (a == b) {
-                if (in_lds) {
-                    sv = sym3(lds + ((size_t)a * oq + j6) * 6, k, l);
-                } else {
-                    sv = sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
-                    for (int o = 0; o < nb; ++o) {
-                        if (o == a) continue;
-                        const int lo = a < o ? a : o, hi = a < o ? o : a;
-                        sv += sym3(w.pracc + ((size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6) * 12, k, l);
-                    }
-                }
+                sv = in_lds ? sym3(lds + ((size_t)a * oq + j6) * 6, k, l) : sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
             } else {
-                const int lo = a < b ? a : b, hi = a < b ? b : a;
-                const int pr = lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1);
-                sv = -sym3(w.pracc + ((size_t)pr * oq + j6) * 12, k, l);
+                const int lo = a < b ? a : b, hi = a < b ? b : a, seg = j6 / 6;
+                const int wi = w.wi_of[lo * oq + j6];
+                const size_t slot = (size_t)w.tile_base[wi >> 6] + (wi & 63) + (size_t)(6 + hi - 1) * 64;  // pair (lo, hi) is row 6 + (hi - 1) of lo's column
+                const double sr = w.s[slot], zr = w.z[slot];
+                const float* nv = c.normals + (pair_index(N, d.first + lo, d.first + hi) * M + seg) * 3;
+                sv = -(zr * fast_rcp(sr + dreg * zr)) * (double)nv[k] * (double)nv[l];
             }
             Sv[p] = sv;
         }
@@ -1750,10 +1740,13 @@ __global__ __launch_bounds__(256) void dummy_kernel(DevSession s) {
 }
 
 #ifdef QP_TRACE
+#ifndef QP_TRACE_BATCH
+#define QP_TRACE_BATCH 0
+#endif
 // developer build: per-iteration checksums of the first batch QP of a mission, written into the mission's coef slot
 #define TRC(slot, expr)                                                         \
     do {                                                                        \
-        if (batch == 0 && pass_index == 0 && iter < 60) {                       \
+        if (batch == QP_TRACE_BATCH && pass_index == 0 && iter < 100) {                       \
             const double v_ = (expr);                                           \
             if (tid == 0) trc[iter * 16 + (slot)] = v_;                         \
         }                                                                       \
@@ -1900,26 +1893,45 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             rank += (co > ci || (co == ci && o < it)) ? 1 : 0;
         }
         w.fperm[rank] = it;
+        w.frank[it] = rank;
     }
     __threadfence_block();
     __syncthreads();
-    // tabulate the constants of the surviving rows: n (sign applied) and rhc = n . d_f - (r_a + r_f)
+    // row storage (see the note above QpWs): tile t holds the control points wi = 64 t .. 64 t + 63; its columns are as long as
+    // its first (= longest) one
+    if (tid == 0) {
+        int base = 0;
+        for (int t = 0; t < d.ntile; ++t) {
+            w.tile_base[t] = base;
+            base += 64 * (d.ncol0 + w.fcnt[w.fperm[(64 * t) / 6]]);
+        }
+        w.tile_base[d.ntile] = base;
+    }
+    for (int wi = tid; wi < nb * d.oq; wi += QP_THREADS) {
+        const int grp = w.fperm[wi / 6], a = grp / M, seg = grp - a * M;
+        w.wi_of[a * d.oq + 6 * seg + wi % 6] = wi;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // tabulate the constants of the surviving frozen rows: the signed normal per (group, neighbour) and, per row,
+    // rh = n . d_f - (r_a + r_f)
     for (int it = tid; it < nb * M * 6; it += QP_THREADS) {
         const int as = it / 6, i = it % 6, a = as / M, seg = as % M, qa = first + a, j6 = 6 * seg + i;
         const int cnt = w.fcnt[as];
         const int* fl = w.flist + (size_t)as * N;
-        const size_t fr0 = (size_t)w.fbase[as] * 6 + i;
+        const int wi = 6 * w.frank[as] + i;
+        const size_t r0 = (size_t)w.tile_base[wi >> 6] + (wi & 63) + (size_t)d.ncol0 * 64;
+        float* nr = w.nrm + (size_t)w.fbase[as] * 3;
         const double ra = c.radius[qa];
         for (int idx = 0; idx < cnt; ++idx) {
             const int f = fl[idx];
             const bool a_first = qa < f;
             const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
-            const double sg = a_first ? 1.0 : -1.0;
-            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
-            const size_t fr = fr0 + (size_t)idx * 6;
-            w.rn0[fr] = n0, w.rn1[fr] = n1, w.rn2[fr] = n2;
-            w.rhc[fr] = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
-                        n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6] - (ra + c.radius[f]);
+            const float sgf = a_first ? 1.0f : -1.0f;
+            const double n0 = (double)(sgf * nv[0]), n1 = (double)(sgf * nv[1]), n2 = (double)(sgf * nv[2]);
+            if (i == 0) nr[3 * idx] = sgf * nv[0], nr[3 * idx + 1] = sgf * nv[1], nr[3 * idx + 2] = sgf * nv[2];
+            w.rh[r0 + (size_t)idx * 64] = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
+                                          n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6] - (ra + c.radius[f]);
         }
     }
     __threadfence_block();
@@ -1944,11 +1956,17 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         }
         return;
     }
-    const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;
+    const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;  // every pair row once
     bool ok = false;
     int it_count = 0, polished = 0, early_tries = 0, fail_reason = 3;
     double gap_next = 0, pres_next = 0, kkt_ipm = 0;
-    double flops = 0, rows_swept = 0;
+    double flops = 0, rows_swept = 0, row_bytes = 0;
+    // ALGORITHMIC HBM bytes of one interior-point iteration (the numerator of the HBM roofline): per row the three
+    // sweeps read (s, z) three times and write them once (64 B), frozen rows also read their constant three times (+24 B); per free
+    // control point the accumulators are written twice and read four times (288 B); the knot blocks are written and read once
+    // (T_j), the two factor blocks per knot written once and read by both substitutions: 8 block transfers of ldb^2 doubles per knot
+    const double bytes_iter = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6) +
+                              64.0 * (double)d.nj * d.ldb * d.ldb;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
     pw.V = w.polish + PL_NC * 14;
@@ -1992,6 +2010,13 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             ok = true;
             break;
         }
+        // complementarity has collapsed (mu < 1e-14) with the primal residual at rounding level while the dual residual sits on
+        // its noise floor (Newton weights of 1e9+ on degenerate active sets: ~5e-9 relative): more iterations change nothing.
+        // The active-set polish below turns this point into the certified optimum; if it is refused, kkt_max reports the floor.
+        if (pres < 1e-9 && dres < 1e-7 && mu < 1e-14) {
+            ok = true;
+            break;
+        }
         PROF(2);
         // EARLY CROSSOVER: the polish returns the exact optimum (KKT-verified on every row) as soon as the interior-point
         // iterate identifies the active set, which happens several iterations before the 1e-10 termination test: try it
@@ -2019,7 +2044,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             }
         }
         // ---- Newton matrix and factorisation
-        assemble_blocks(c, lds);
+        assemble_blocks(c, lds, io.dreg);
         PROF(3);
         __threadfence_block();
         __syncthreads();
@@ -2079,9 +2104,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __threadfence_block();
         __syncthreads();
         // ---- step, wide neighbourhood (no product below 1e-3 * mu(alpha)) and the next iteration's first sweep in ONE pass:
-        // the step is applied speculatively ((s, z) += alpha (ds, dz), x += alpha dx) while the same sweep evaluates the
-        // neighbourhood test and the new weights/residuals.  In the rare case the test fails the sweep is repeated with the
-        // difference to the shorter step (0.8 alpha), which also corrects the iterate.
+        // x += alpha dx is applied speculatively, the sweep reads the OLD row state, recomputes the step, writes the NEW state
+        // into the second pair of arrays, evaluates the neighbourhood test on it and builds the next iteration's weights and
+        // residuals.  In the rare case the test fails the sweep is repeated from the (untouched) old state with 0.8 alpha.
         double applied = 0;
         for (int bt = 0; bt < 40; ++bt) {
             const double delta = alpha - applied;
@@ -2091,7 +2116,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             }
             __threadfence_block();
             __syncthreads();
-            io.alpha = delta, io.sum0 = 0, io.vmax = 0, io.vmin = 1e300;
+            io.alpha = alpha, io.sum0 = 0, io.vmax = 0, io.vmin = 1e300;
             SWEEP(PASS_UPBUILD);
             applied = alpha;
             gap_next = block_reduce(io.sum0, 0, red);
@@ -2103,7 +2128,18 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             if (pmin >= 1e-3 * gap_next / nrows_free) break;
             alpha *= 0.8;
         }
+        // the new state becomes the current one
+        {
+            double* t0 = c.w.s;
+            c.w.s = c.w.s2, c.w.s2 = t0;
+            t0 = c.w.z, c.w.z = c.w.z2, c.w.z2 = t0;
+#if QP_WAVES_PER_EU < 4
+            if (tid == 0) c_lds.w.s = c.w.s, c_lds.w.s2 = c.w.s2, c_lds.w.z = c.w.z, c_lds.w.z2 = c.w.z2;
+#endif
+            __syncthreads();
+        }
         rows_swept += 2 * nrows_free;
+        row_bytes += bytes_iter;
         PROF(10);
         PROF(11);
     }
@@ -2153,6 +2189,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         scal[SC_KKT_MAX] = fmax(scal[SC_KKT_MAX], kkt);
         scal[SC_FLOPS] += flops;
         scal[SC_ROWS] += rows_swept;
+        scal[SC_ROW_BYTES] += row_bytes;
     }
     PROF_FLUSH(scal);
 }
