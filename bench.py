@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-mission latency leg (profiling runs: keeps the kernel list clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of the launcher)")
     ap.add_argument("--dry-run", action="store_true", help="launcher test: initialise the ranks, print the JSON skeleton, plan nothing")
     args = ap.parse_args()
@@ -324,7 +325,7 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s (reference-equivalent sample bytes, not physical)",
                              "frac": sfc_bytes / (corridor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "samples_per_step": ct["sfc_samples"]},
         }
-        if N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint:
+        if N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint and not args.no_latency:
             try:
                 out["latency_ms_single_mission"] = single_mission_latency(mission, param, worlds[0], plans[0])
             except Exception as e:

@@ -6,16 +6,17 @@ TAG=${1:-r01}; K=${2:-1000}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --missions-per-gpu $K > $OUT/bench.log 2>&1
+python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --no-cpu-baseline > $OUT/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --no-cpu-baseline --no-latency > $OUT/kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $OUT/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $OUT/pmc_mfma.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 python tools/pmc_summary.py $(dirname $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)) $(dirname $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)) ${TAG}tmp $K > $OUT/pmc_summary.txt 2>&1
-cp profiles/${TAG}tmp_pmc.json $OUT/pmc.json 2>/dev/null
+mv profiles/${TAG}tmp_pmc.json $OUT/pmc.json 2>/dev/null
 python - <<PY > $OUT/pmc_mfma.txt 2>&1
 import csv, glob, collections
 f = glob.glob("$OUT/pmc_mfma/**/*counter_collection.csv", recursive=True)[0]
