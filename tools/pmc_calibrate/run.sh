@@ -3,6 +3,7 @@
 OUT=$PWD/gpurun_out/pmc_calib; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 BIN=$PWD/tools/pmc_calibrate/calib
+[ -x $BIN ] || hipcc --offload-arch=gfx950 -O3 -o $BIN $PWD/tools/pmc_calibrate/calib.hip
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- $BIN > $OUT/$c.log 2>&1; done
 cd - > /dev/null
