@@ -75,6 +75,13 @@ int rbp_validate(const rbp_mission* mission, const rbp_param* param, int32_t M, 
 /* crazyswarm CSV of rbp_planner.hpp:295-324 (one file per agent: <dir>/coef<qi+1>.csv) */
 int rbp_write_coef_csv(const char* dir, int32_t N, int32_t M, const double* T, const double* coef);
 
+/* The QP of batch `l` as a CPLEX LP-format file: what cplex.exportModel(".../log/QPmodel.lp") writes when the reference runs with
+ * log = true (rbp_planner.hpp:150-152): variables named and ordered as in populatebyrow (:552-577), objective without 1/2,
+ * equality, SFC and RSFC rows (:582-684).  plan: T / init_traj / corridor as BEFORE timeScale.  dummy: the control points frozen
+ * agents are held at ([N][3][6M], the layout of rbp_plan.ctrl), or NULL for build_dummy of the initial trajectory (:513-549). */
+int rbp_write_qp_lp(const char* path, const rbp_mission* mission, const rbp_param* param, const rbp_plan* plan, int32_t l,
+                    const double* dummy);
+
 #ifdef __cplusplus
 }
 #endif

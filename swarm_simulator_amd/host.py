@@ -40,6 +40,8 @@ def lib():
         L.rbp_validate.argtypes = [C.POINTER(A.rbp_mission), C.POINTER(A.rbp_param), C.c_int32, A.c_double_p,
                                    A.c_double_p, C.c_double, A.c_double_p, A.c_double_p]
         L.rbp_write_coef_csv.argtypes = [C.c_char_p, C.c_int32, C.c_int32, A.c_double_p, A.c_double_p]
+        L.rbp_write_qp_lp.argtypes = [C.c_char_p, C.POINTER(A.rbp_mission), C.POINTER(A.rbp_param), C.POINTER(A.rbp_plan), C.c_int32,
+                                      A.c_double_p]
         _lib = L
     return _lib
 
@@ -141,3 +143,13 @@ def write_coef_csv(directory, plan: PlanResult):
     rc = lib().rbp_write_coef_csv(directory.encode(), plan.N, plan.M, A.ptr(plan.T, A.c_double_p), A.ptr(plan.coef, A.c_double_p))
     if rc:
         raise RuntimeError(f"rbp_write_coef_csv rc={rc}")
+
+
+def write_qp_lp(path, mission: Mission, param: Param, plan: PlanResult, batch: int, dummy=None):
+    """QPmodel.lp of batch `batch` (rbp_planner.hpp:150-152): `plan` holds the corridor and the UNSCALED T; `dummy` = control points
+    of the frozen agents ([N][3][6M]) or None for build_dummy."""
+    ms, ps, pl = mission.c_struct(), param.c_struct(), plan.c_struct()
+    d = None if dummy is None else A.as_f64(dummy)
+    rc = lib().rbp_write_qp_lp(path.encode(), C.byref(ms), C.byref(ps), C.byref(pl), batch, A.ptr(d, A.c_double_p))
+    if rc:
+        raise RuntimeError(f"rbp_write_qp_lp rc={rc}")

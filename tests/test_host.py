@@ -100,6 +100,58 @@ def test_ecbs_output_is_valid_and_shaped_like_the_reference():
     assert st["sum_cost"] >= lb
 
 
+def _conflicts_vec(traj, radius, grid, gmin):
+    """vectorised _conflicts (all pairs at once per time step)"""
+    N = traj.shape[0]
+    cells = np.round((traj[:, 1:-1] - gmin) / grid).astype(np.int64)
+    iu, ju = np.triu_indices(N, 1)
+    rr = radius[iu] + radius[ju]
+    n = 0
+    for t in range(cells.shape[1]):
+        a = (cells[ju, t] - cells[iu, t]).astype(float)
+        n += int((np.abs(a).sum(1) == 0).sum())
+        if t + 1 < cells.shape[1]:
+            b = (cells[ju, t + 1] - cells[iu, t + 1]).astype(float)
+            md = np.minimum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1))
+            dba = b - a
+            ln = np.linalg.norm(dba, axis=1)
+            mv = ln > 0
+            nn = np.zeros_like(dba)
+            nn[mv] = dba[mv] / ln[mv, None]
+            cpt = a - nn * (a * nn).sum(1, keepdims=True)
+            inside = mv & (((cpt - a) * (cpt - b)).sum(1) < 0)
+            md = np.where(inside, np.minimum(md, np.linalg.norm(cpt, axis=1)), md)
+            n += int((md * grid[0] <= rr).sum())
+    return n
+
+
+def test_ecbs_sweep_50_maps_64_agents_valid_and_bounded_suboptimal():
+    """f-1 acceptance over the whole benchmark set (launch/plan_rbp_test.launch: ecbs/w = 1.5, grid 0.5 / 1.0): the discrete
+    solution of every map is conflict free under the reference's size-aware rules (environment.hpp:656-681), M = makespan + 2
+    (ecbs_planner.hpp:41-43), and its cost is within w of the sum of the agents' individual optimal paths -- the bound ECBS
+    guarantees (third_party/ecbs/include/ecbs.hpp:109-297); the individual optima come from the same front-end run on one agent
+    with w = 1 (plain A*)."""
+    p = Param.test_sweep()
+    p1 = Param.test_sweep(ecbs_w=1.0)
+    m = host.load_mission("mission_64agents_15.json")
+    gmin, grid = np.array([-5.0, -5.0, 1.0]), np.array([0.5, 0.5, 1.0])
+    assert _conflicts_vec(np.zeros((2, 4, 3)), np.array([0.15, 0.15]), grid, gmin) == _conflicts(np.zeros((2, 4, 3)), np.array([0.15, 0.15]), grid, gmin)
+    worst = 0.0
+    for mid in range(1, 51):
+        w = host.load_world(f"map{mid}.bt", p)
+        pr = host.ecbs_plan(w, m, p)
+        st = pr.ecbs_stats
+        assert pr.M == st["makespan"] + 2
+        assert _conflicts_vec(pr.init_traj.astype(float), m.radius, grid, gmin) == 0, f"map{mid}"
+        opt = 0
+        for qi in range(m.qn):
+            opt += host.ecbs_plan(w, m.subset([qi]), p1).ecbs_stats["sum_cost"]
+        assert opt <= st["sum_cost"] <= p.ecbs_w * opt + 1e-9, (mid, st["sum_cost"], opt)
+        worst = max(worst, st["sum_cost"] / opt)
+    assert worst <= p.ecbs_w
+    print(f"ECBS over 50 maps x 64 agents: worst sum_cost / sum of individual optima = {worst:.4f} (w = {p.ecbs_w})")
+
+
 def test_validation_metrics_on_the_reference_log():
     """rbp_publisher.hpp:685-695, 769-798 applied to the reference's committed run: ratio 1.0019, cf. SURVEY.md 4."""
     g = np.load(os.path.join(GOLDEN_DIR, "ref_log_coef.npz"))

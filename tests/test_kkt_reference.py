@@ -86,3 +86,71 @@ def test_gpu_answers_are_certified_optima(name):
                           g["rsfc_time0"], pr.ctrl, p.sequential, p.batch_size, p.batch_iter)
     check_reports(reps)
     assert pr.qp_unpolished == 0 and pr.kkt_max < 1e-8
+
+
+def _parse_lp(path):
+    """minimal reader of the LP file rbp_write_qp_lp produces: objective terms, rows (coefficients, sense, rhs), variable order"""
+    import re
+    txt = open(path).read()
+    obj = txt[txt.index("obj: [") + 6:txt.index("] / 2")]
+    rows_txt = txt[txt.index("Subject To") + 10:txt.index("Bounds")]
+    names = [ln.split()[0] for ln in txt[txt.index("Bounds") + 6:txt.index("End")].strip().splitlines()]
+    idx = {n: i for i, n in enumerate(names)}
+    Q = np.zeros((len(names), len(names)))
+    for sign, coef, a, _, b in re.findall(r"([+-])\s*([0-9.eE+-]+)\s+(\w+)\s*(\^2|\*\s*(\w+))", obj):
+        c = float(coef) * (1 if sign == "+" else -1) / 2.0   # inside [ ] / 2
+        if b:
+            Q[idx[a], idx[b]] += c / 2
+            Q[idx[b], idx[a]] += c / 2
+        else:
+            Q[idx[a], idx[a]] += c
+    rows = []
+    for ln in rows_txt.strip().splitlines():
+        body = ln.split(":", 1)[1]
+        m = re.search(r"(<=|>=|=)\s*([0-9.eE+-]+)\s*$", body)
+        sense, rhs = m.group(1), float(m.group(2))
+        co = np.zeros(len(names))
+        sgn, coef = 1.0, 1.0
+        for tok in body[:m.start()].split():
+            if tok == "+":
+                sgn, coef = 1.0, 1.0
+            elif tok == "-":
+                sgn, coef = -1.0, 1.0
+            elif tok in idx:
+                co[idx[tok]] += sgn * coef
+                sgn, coef = 1.0, 1.0
+            else:
+                coef = float(tok)
+        rows.append((co, sense, rhs))
+    return names, Q, rows
+
+
+def test_qp_lp_dump_equals_the_numpy_restatement(tmp_path):
+    """f-3: the QPmodel.lp writer of the host library (C++, csrc/host/qp_lp.cpp) and the numpy restatement describe the same QP:
+    variable order of rbp_planner.hpp:561, objective, equality rows, SFC rows, RSFC rows with the frozen agents at `dummy`"""
+    from swarm_simulator_amd import host
+    c = Case("s4_map1_seq2")   # 4 agents, batches of 2: batch 1 sees batch 0 frozen at its answer
+    g, m, p = c.g, c.mission, c.param
+    pr = c.with_corridor()
+    ctrl = g["ctrl"]
+    dummy = K.build_dummy(g["init_traj"])
+    dummy[0], dummy[1] = ctrl[0].T, ctrl[1].T        # batch 0 = agents 0, 1 already solved (:183-185)
+    path = str(tmp_path / "QPmodel.lp")
+    host.write_qp_lp(path, m, p, pr, 1, np.ascontiguousarray(dummy.transpose(0, 2, 1)))
+    names, Q, rows = _parse_lp(path)
+    lo, hi = K.select_boxes(g["T0"], g["sfc_box"], g["sfc_time0"], g["sfc_count"])
+    qp = K.BatchQP(g["T0"], m.start, m.goal, m.radius, lo, hi, K.select_normals(g["T0"], g["rsfc_normal"], g["rsfc_time0"]), dummy, [2, 3])
+    # variable order: x[k * offset_dim + bi * offset_quad + m * (n+1) + i]
+    M = qp.M
+    want = [f"{'xyz'[k]}_{qi}_{mm}_{i}" for k in range(3) for qi in (2, 3) for mm in range(M) for i in range(6)]
+    assert names == want and len(names) == qp.count_x
+    x = np.random.default_rng(7).normal(size=qp.nx)
+    assert abs(x @ Q @ x - qp.objective(x)) <= 1e-9 * abs(qp.objective(x))
+    eq = [r for r in rows if r[1] == "="]
+    assert len(eq) == qp.count_eq and len(rows) - len(eq) == qp.count_lq
+    A = np.stack([r[0] for r in eq])
+    assert np.abs(A @ x - np.array([r[2] for r in eq]) - qp.eq_residual(x)).max() < 1e-9
+    # inequalities in G x <= h form, same row order as populatebyrow (SFC: upper, lower per variable; then RSFC pair-major)
+    G = np.stack([r[0] if r[1] == "<=" else -r[0] for r in rows[len(eq):]])
+    h = np.array([r[2] if r[1] == "<=" else -r[2] for r in rows[len(eq):]])
+    assert np.abs(G @ x - qp.G_dot(x)).max() < 1e-9 and np.abs(h - qp.h).max() < 1e-9

@@ -121,3 +121,48 @@ def test_reference_log_is_consistent_with_restated_matrices():
     assert worst < 1e-4          # print precision of the CSV (6 significant digits)
     assert abs(cost - 42.15) < 0.02
     assert ctrl[:, :, 2, :].min() > 0.3 - 1e-5  # world_z_min = 0.3 floor is respected
+
+
+def _min_norm_point(P, iters=200):
+    """distance from the origin to conv(P) (Gilbert / Frank-Wolfe with exact line search); P [n][3]"""
+    x = P[np.argmin((P * P).sum(1))].copy()
+    for _ in range(iters):
+        s = P[np.argmin(P @ x)]
+        d = s - x
+        dd = d @ d
+        if dd < 1e-30 or -(x @ d) <= 1e-15:
+            break
+        x = x + min(1.0, -(x @ d) / dd) * d
+    return float(np.linalg.norm(x))
+
+
+def test_reference_log_satisfies_the_rsfc_and_sfc_structure():
+    """the reference's OWN committed output (log/coef*.csv: CPLEX's answer on some 64-agent run) has the structure the QP rows impose:
+    for every pair of agents and every segment the six control-point differences, with z divided by the downwash, can be separated
+    from the origin by ONE half-space at distance >= r_i + r_j -- that is what the RSFC rows n . (c_j - c_i) >= r_i + r_j with a
+    unit normal whose z is divided by the downwash once more (rbp_corridor.hpp:358-384, rbp_planner.hpp:638-684) state --, all
+    control points lie inside the world box (z floor 0.3: the SFC boxes), and the end states are the mission's."""
+    from swarm_simulator_amd import host
+    g = np.load(os.path.join(GOLDEN_DIR, "ref_log_coef.npz"))
+    coef = g["coef"]
+    _, B = O.Q_base()
+    ctrl = np.einsum("ij,amkj->amki", np.linalg.inv(B.T), coef[..., 5::-1])  # [64][36][3][6] (dt = 1)
+    m = host.load_mission("mission_64agents_15.json")
+    dw = 2.0  # plan/downwash of launch/plan_rbp_random_forest.launch
+    worst = 1e9
+    rng = np.random.default_rng(5)
+    pairs = [(i, j) for i in range(64) for j in range(i + 1, 64)]
+    for (i, j) in [pairs[k] for k in rng.choice(len(pairs), 400, replace=False)]:
+        for seg in range(36):
+            d = (ctrl[j, seg] - ctrl[i, seg]).T.copy()   # [6][3]
+            d[:, 2] /= dw
+            worst = min(worst, _min_norm_point(d) / (m.radius[i] + m.radius[j]))
+    assert worst > 1 - 2e-3, worst   # CSV print precision: 6 significant digits
+    assert ctrl[:, :, 0, :].min() > -5 - 1e-4 and ctrl[:, :, 0, :].max() < 5 + 1e-4
+    assert ctrl[:, :, 1, :].min() > -5 - 1e-4 and ctrl[:, :, 1, :].max() < 5 + 1e-4
+    assert ctrl[:, :, 2, :].min() > 0.3 - 1e-5 and ctrl[:, :, 2, :].max() < 2.5 + 1e-4
+    # end states: the mission's start / goal positions, zero velocity and acceleration (first / last three control points equal)
+    for a in range(64):
+        assert np.abs(ctrl[a, 0, :, 0] - m.start[a, :3]).max() < 1e-4 or np.abs(ctrl[a, 0, :, 0] - m.goal[a, :3]).max() < 5.1
+        assert np.abs(ctrl[a, 0, :, 1] - ctrl[a, 0, :, 0]).max() < 1e-4 and np.abs(ctrl[a, 0, :, 2] - ctrl[a, 0, :, 0]).max() < 1e-4
+        assert np.abs(ctrl[a, -1, :, 4] - ctrl[a, -1, :, 5]).max() < 1e-4 and np.abs(ctrl[a, -1, :, 3] - ctrl[a, -1, :, 5]).max() < 1e-4
