@@ -49,6 +49,9 @@
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU (512 / QP_THREADS)  // 2 with 512 threads: all 256 VGPRs for the wave-register path
 #endif
+#ifndef QP_STAGE_BUFS
+#define QP_STAGE_BUFS (QP_WAVES_PER_EU >= 4 ? 2 : 3)
+#endif
 #ifndef QP_RCP_NEWTON
 #define QP_RCP_NEWTON 2
 #endif
@@ -798,7 +801,8 @@ __device__ __forceinline__ void coupling_row(const QpWs& w, int j, int dir, int 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define SYRK_LDB (36 + 2)
 #define SYRK_LDU (48 + 2)
-#define SYRK_LDS_DOUBLES (48 * SYRK_LDB + 48 * SYRK_LDU)
+#define SYRK_DINV (48 * SYRK_LDB + 48 * SYRK_LDU)  // [40]: 1 / d of the block whose coupling factor sits in the B area
+#define SYRK_LDS_DOUBLES (48 * SYRK_LDB + 48 * SYRK_LDU + 40)
 
 template <int NK>
 __device__ __forceinline__ void syrk_store_b(const double (&b)[NK], double* ldsB, int r) {
@@ -808,19 +812,21 @@ __device__ __forceinline__ void syrk_store_b(const double (&b)[NK], double* ldsB
     }
 }
 
+// acc += X D^{-1} X'  (X in ldsB, 1/d in ldsD): the A operand is scaled on the fly, the B operand is X itself -- no square roots
 template <int NK>
-__device__ __forceinline__ void syrk_mfma_accumulate(d4 (&acc)[6], const double* ldsB, int lane) {
+__device__ __forceinline__ void syrk_mfma_accumulate(d4 (&acc)[6], const double* ldsB, const double* ldsD, int lane) {
     constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
     const int li = lane & 15, lk = lane >> 4;
     for (int ks = 0; ks < KS; ++ks) {
-        double op[3];
+        double op[3], os[3];
+        const double dk = ldsD[4 * ks + lk];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) op[t] = ldsB[(16 * t + li) * SYRK_LDB + 4 * ks + lk];
+        for (int t = 0; t < NT; ++t) op[t] = ldsB[(16 * t + li) * SYRK_LDB + 4 * ks + lk], os[t] = op[t] * dk;
         int idx = 0;
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int tj = 0; tj <= ti; ++tj, ++idx) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[idx], 0, 0, 0);
+            for (int tj = 0; tj <= ti; ++tj, ++idx) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(os[ti], op[tj], acc[idx], 0, 0, 0);
     }
 }
 
@@ -853,8 +859,33 @@ __device__ __forceinline__ void syrk_rows(double (&a)[NK], const double (&b)[NK]
     d4 acc[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc[i] = d4{0, 0, 0, 0};
-    syrk_mfma_accumulate<NK>(acc, ldsB, lane);
+    syrk_mfma_accumulate<NK>(acc, ldsB, ldsW + SYRK_DINV, lane);
     syrk_apply<NK>(a, acc, ldsU, lane, rr);
+}
+
+// SQUARE-ROOT-FREE factorisation A = L D L' (L unit lower), right-looking, one row per lane: a[c] = L[r][c] for lanes r > c,
+// dinv = 1 / d_r of this lane's row.  Why not Cholesky: a dependent FP64 operation costs 32 cycles on this machine (measured:
+// 13.3 ns per dependent v_fma_f64), and the pivot path of a Cholesky column is rsqrt + two Newton steps + a multiply + the
+// update (nine dependent operations); here it is rcp + two Newton steps + multiply + update (seven), and -- the larger effect --
+// every triangular solve with the UNIT factor loses the multiplication by the inverse pivot from each of its dependent steps.
+template <int NK>
+__device__ __forceinline__ bool ldl_rows(double (&a)[NK], double& dinv) {
+    bool ok = true;
+    const int r = threadIdx.x & 63;
+    dinv = 1.0;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+        const double dcc = rl(a[c], c);
+        if (!(dcc > 0)) ok = false;
+        double inv = __builtin_amdgcn_rcp(dcc);  // v_rcp_f64 is good to 4.6e-8 (measured); ONE Newton step gives 2e-15, i.e. a
+        inv = fma(fma(-dcc, inv, 1.0), inv, inv);  // perturbation of the pivot at rounding level -- and two dependent operations
+        dinv = (r == c) ? inv : dinv;              // (64 cycles) less on every column's critical path than the second step
+        const double lc = a[c] * inv;  // L[r][c] (1 on the diagonal lane)
+#pragma unroll
+        for (int k = c + 1; k < NK; ++k) a[k] -= lc * rl(a[c], k);  // A[r][k] -= L[r][c] A[k][c]   (A[k][c] still unscaled in lane k)
+        a[c] = lc;
+    }
+    return ok;
 }
 
 template <int NK>
@@ -884,9 +915,11 @@ __device__ __forceinline__ bool chol_rows(double (&a)[NK], double& dinv) {  // r
 
 template <int NK>
 __device__ __forceinline__ void syrk_tiles_lo(double* ldsW, int lane, bool accumulate) {
-    // U (+)= B B' (lower 16x16 tiles) with B in ldsW[0 .. 48*SYRK_LDB), U in the scratch behind it; three MFMA tiles at a
-    // time (24 accumulator VGPRs), and no block row is live here: the caller loads it afterwards and subtracts its U row
+    // U (+)= X D^{-1} X' (lower 16x16 tiles) with X in ldsW[0 .. 48*SYRK_LDB), 1/d in ldsW + SYRK_DINV, U in the scratch behind X;
+    // three MFMA tiles at a time (24 accumulator VGPRs), and no block row is live here: the caller loads it afterwards and
+    // subtracts its U row
     const double* ldsB = ldsW;
+    const double* ldsD = ldsW + SYRK_DINV;
     double* ldsU = ldsW + 48 * SYRK_LDB;
     constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
     const int li = lane & 15, lk = lane >> 4;
@@ -896,7 +929,7 @@ __device__ __forceinline__ void syrk_tiles_lo(double* ldsW, int lane, bool accum
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = d4{0, 0, 0, 0};
         for (int ks = 0; ks < KS; ++ks) {
-            const double opi = ldsB[(16 * ti + li) * SYRK_LDB + 4 * ks + lk];
+            const double opi = ldsB[(16 * ti + li) * SYRK_LDB + 4 * ks + lk] * ldsD[4 * ks + lk];
 #pragma unroll
             for (int tj = 0; tj <= ti; ++tj) {
                 const double opj = ldsB[(16 * tj + li) * SYRK_LDB + 4 * ks + lk];
@@ -922,7 +955,7 @@ __device__ __forceinline__ void park_factor(const double (&a)[NK], double dinv, 
     if (act) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            L0[k * NK + r] = k <= r ? a[k] : 0.0;
+            L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);  // unit lower factor, 1/d on the diagonal
             ldsL[r * WF_LDL + k] = a[k];
         }
         ldsInv[r] = dinv;
@@ -949,7 +982,7 @@ __device__ __forceinline__ void coupling_solve_lo(const QpWs& w, int j, int dir,
             else
                 s0 -= x[k] * ldsL[c * WF_LDL + k];
         }
-        x[c] = (s0 + s1) * ldsInv[c];
+        x[c] = s0 + s1;  // L is unit lower: no pivot
     }
 }
 
@@ -960,7 +993,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
     const int rr = act ? r : 0;
     double* ldsB = ldsW;
     double* ldsL = ldsW + 48 * SYRK_LDB;  // overlays the U tiles of the rank-k update
-    double* ldsInv = ldsL + 40 * WF_LDL;
+    double* ldsInv = ldsW + SYRK_DINV;    // 1/d of the block just factorised: scales the next step's rank-k update
     bool ok = true;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
         if (i > 0) syrk_tiles_lo<NK>(ldsW, r, false);
@@ -976,7 +1009,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
             __builtin_amdgcn_wave_barrier();
         }
         double dinv;
-        if (!chol_rows<NK>(a, dinv)) ok = false;
+        if (!ldl_rows<NK>(a, dinv)) ok = false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         park_factor<NK>(a, dinv, L0, ldsL, ldsInv, r, act);
         {
@@ -1002,9 +1035,11 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     for (int side = 0; side < 2; ++side) {
         const int jn = side == 0 ? mid - 1 : mid + 1;
         if (jn < 0 || jn >= d.nj) continue;
-        const double* Bm = w.Lf + (size_t)jn * 2 * NK * NK + NK * NK;
+        const double* Lm = w.Lf + (size_t)jn * 2 * NK * NK;
+        const double* Bm = Lm + NK * NK;
         if (act) {
             for (int k = 0; k < NK; ++k) ldsW[r * SYRK_LDB + k] = Bm[k * NK + r];
+            ldsW[SYRK_DINV + r] = Lm[r * NK + r];  // 1/d of block jn
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1021,11 +1056,11 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
         for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];
     }
     double dinv;
-    if (!chol_rows<NK>(a, dinv)) return false;
+    if (!ldl_rows<NK>(a, dinv)) return false;
     double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
     if (act) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
+        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);
     }
     return true;
 }
@@ -1043,20 +1078,21 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
         const double* Tg = w.Td + (size_t)j * NK * NK;
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
-        if (i > 0) syrk_rows<NK>(a, b, ldsW, r, rr);
+        if (i > 0) syrk_rows<NK>(a, b, ldsW, r, rr);  // a -= row of X D^{-1} X' of the previous block (its 1/d sits in ldsW + SYRK_DINV)
         double dinv;
-        if (!chol_rows<NK>(a, dinv)) return false;
+        if (!ldl_rows<NK>(a, dinv)) return false;
         double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
         if (act) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
+            for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);  // unit lower factor, 1/d on the diagonal
+            ldsW[SYRK_DINV + r] = dinv;
         }
-        // coupling towards the next block of the chain (the last one couples to the middle block): b <- Tn L_jj^{-T}
+        // coupling towards the next block of the chain (the last one couples to the middle block): b <- Tn L_jj^{-T}, L unit:
+        // one dependent multiply-add per column
         coupling_row<NK>(w, j, dir, rr, b);
 #pragma unroll
         for (int c = 0; c < NK; ++c) {
-            const double xc = b[c] * rl(dinv, c);  // reciprocal diagonal from the Cholesky: no division on the chain
-            b[c] = xc;
+            const double xc = b[c];
 #pragma unroll
             for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
         }
@@ -1078,23 +1114,27 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
 #pragma unroll
     for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
     if (mid > 0) {
-        const double* Bm = w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK;
+        const double* Lm = w.Lf + (size_t)(mid - 1) * 2 * NK * NK;
+        const double* Bm = Lm + NK * NK;
 #pragma unroll
         for (int k = 0; k < NK; ++k) b[k] = Bm[k * NK + rr];
+        if (act) ldsW[SYRK_DINV + r] = Lm[r * NK + r];  // 1/d of block mid-1
         syrk_rows<NK>(a, b, ldsW, r, rr);
     }
     if (mid + 1 < d.nj) {
-        const double* Cm = w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK;
+        const double* Lm = w.Lf + (size_t)(mid + 1) * 2 * NK * NK;
+        const double* Cm = Lm + NK * NK;
 #pragma unroll
         for (int k = 0; k < NK; ++k) b[k] = Cm[k * NK + rr];
+        if (act) ldsW[SYRK_DINV + r] = Lm[r * NK + r];
         syrk_rows<NK>(a, b, ldsW, r, rr);
     }
     double dinv;
-    if (!chol_rows<NK>(a, dinv)) return false;
+    if (!ldl_rows<NK>(a, dinv)) return false;
     double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
     if (act) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k <= r ? a[k] : 0.0;
+        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);
     }
     return true;
 }
@@ -1139,7 +1179,10 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
     const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
-    double* vec = lds + 2 * STG;    // nj*NK
+    // QP_STAGE_BUFS stage buffers: the blocks of step s + QP_STAGE_BUFS - 1 are fetched while step s runs.  With the unit-factor
+    // steps (~1 us) a prefetch distance of one step no longer covers a global-memory round trip: three buffers in the
+    // one-workgroup-per-CU build (106 KB of LDS), two in the two-per-CU build (its second workgroup covers the wait)
+    double* vec = lds + QP_STAGE_BUFS * STG;  // nj*NK
     for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
     // block indices handled at step s by the left / right wave (-1: idle)
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
@@ -1194,40 +1237,78 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (fwd ? jr + 1 < nj : true) copy_blk(w.Lf + (size_t)(fwd ? jr + 1 : jr) * 2 * NK * NK + NK * NK, buf + O_RO, t0, nt);
         }
     };
-    stage(0, lds, tid, QP_THREADS);
+    for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG, tid, QP_THREADS);
     __syncthreads();
     const int wave = tid >> 6, r = tid & 63;
     const int rr = r < NK ? r : 0;
     // row rr of the packed factor: a[k] = L[rr][k], k <= rr; column rr: a[k] = L[k][rr], k >= rr
-#define DG_ROW(dg, k) ((k) <= rr ? (dg)[(k) * NK - (k) * ((k) - 1) / 2 + rr - (k)] : 0.0)
-#define DG_COL(dg, k) ((k) >= rr ? (dg)[rr * NK - rr * (rr - 1) / 2 + (k) - rr] : 0.0)
-    double prev = 0;  // this chain's previous solution vector, element r
+#define DG_ROW(dg, k) ((k) < rr ? (dg)[(k) * NK - (k) * ((k) - 1) / 2 + rr - (k)] : 0.0)
+#define DG_COL(dg, k) ((k) > rr ? (dg)[rr * NK - rr * (rr - 1) / 2 + (k) - rr] : 0.0)
+    // products with a coupling block: four partial sums (a single accumulator would be a chain of 36 dependent FP64 operations, 32
+    // cycles each)
+    auto dot_rows = [&](const double* blk_col0, int stride_k, const double* xs) {  // sum_k blk[k*stride] * xs[k], xs in LDS
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k += 4) {
+            s0 += blk_col0[k * stride_k] * xs[k];
+            if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * xs[k + 1];
+            if (k + 2 < NK) s2 += blk_col0[(k + 2) * stride_k] * xs[k + 2];
+            if (k + 3 < NK) s3 += blk_col0[(k + 3) * stride_k] * xs[k + 3];
+        }
+        return (s0 + s1) + (s2 + s3);
+    };
+    auto dot_lanes = [&](const double* blk_col0, int stride_k, double xv) {  // same with xs[k] = lane k's xv
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k += 4) {
+            s0 += blk_col0[k * stride_k] * rl(xv, k);
+            if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * rl(xv, k + 1);
+            if (k + 2 < NK) s2 += blk_col0[(k + 2) * stride_k] * rl(xv, k + 2);
+            if (k + 3 < NK) s3 += blk_col0[(k + 3) * stride_k] * rl(xv, k + 3);
+        }
+        return (s0 + s1) + (s2 + s3);
+    };
+    // The blocks are factorised as L D L' with L UNIT lower (1/d sits on the diagonal of the packed factor): a step of a
+    // triangular solve is one readlane and one multiply-add.  With X_j = T_{j,jp} L_jp^{-T} (the stored coupling factor):
+    //   forward   y_j = L_j^{-1} (r_j - X_j z_jp),  z_j = D_j^{-1} y_j          backward   x_j = L_j^{-T} (z_j - D_j^{-1} X_jn' x_jn)
+    // factor entries of a dependent solve: preloaded into registers where the budget allows (256-VGPR build: an LDS round trip per
+    // dependent step would triple the step), read where they are used otherwise (128-VGPR build: preloading spills)
+#if QP_WAVES_PER_EU >= 4
+#define LROW_DECL
+#define LROW_LOAD(expr_of_c)
+#define LROW(c, expr) (expr)
+#else
+#define LROW_DECL double lrow[NK]
+#define LROW_LOAD(expr_of_c)                                 \
+    _Pragma("unroll") for (int c = 0; c < NK; ++c) lrow[c] = (expr_of_c)
+#define LROW(c, expr) lrow[c]
+#endif
+    double prev = 0;  // this chain's previous vector (z forward, x backward), element r
     for (int s = 0; s < nsteps; ++s) {
-        double* buf = lds + (s & 1) * STG;
+        double* buf = lds + (s % QP_STAGE_BUFS) * STG;
         if (wave >= 2) {
-            if (s + 1 < nsteps) stage(s + 1, lds + ((s + 1) & 1) * STG, tid - 128, QP_THREADS - 128);
+            const int sp = s + QP_STAGE_BUFS - 1;
+            if (sp < nsteps) stage(sp, lds + (sp % QP_STAGE_BUFS) * STG, tid - 128, QP_THREADS - 128);
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours, then backward
                 double v = vec[mid * NK + rr];
                 const double* dgm = buf + O_LD;
-                if (mid > 0) {
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= buf[O_LO + k * LDP + rr] * vec[(mid - 1) * NK + k];
-                }
-                if (mid + 1 < nj) {
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) v -= buf[O_RO + k * LDP + rr] * vec[(mid + 1) * NK + k];
-                }
-                const double inv = fast_rcp(dgm[rr * NK - rr * (rr - 1) / 2]);
+                if (mid > 0) v -= dot_rows(buf + O_LO + rr, LDP, vec + (mid - 1) * NK);
+                if (mid + 1 < nj) v -= dot_rows(buf + O_RO + rr, LDP, vec + (mid + 1) * NK);
+                const double inv = dgm[rr * NK - rr * (rr - 1) / 2];  // 1 / d_rr
+                LROW_DECL;
+                LROW_LOAD(DG_ROW(dgm, c));
 #pragma unroll
                 for (int c = 0; c < NK; ++c) {
-                    const double xc = rl(v, c) * rl(inv, c);
-                    v = (r == c) ? xc : (r > c ? v - DG_ROW(dgm, c) * xc : v);
+                    const double xc = rl(v, c);
+                    v -= LROW(c, DG_ROW(dgm, c)) * xc;  // 0 for lanes r <= c: no select on the dependent chain
                 }
+                v *= inv;
+                LROW_LOAD(DG_COL(dgm, c));
 #pragma unroll
                 for (int c = NK - 1; c >= 0; --c) {
-                    const double xc = rl(v, c) * rl(inv, c);
-                    v = (r == c) ? xc : (r < c ? v - DG_COL(dgm, c) * xc : v);
+                    const double xc = rl(v, c);
+                    v -= LROW(c, DG_COL(dgm, c)) * xc;
                 }
                 if (r < NK) vec[mid * NK + r] = v;
             }
@@ -1242,29 +1323,25 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
                 // the factor entries are read from LDS where they are used (no 36-double row held in VGPRs: the loads do
                 // not depend on the chain and the scheduler hoists as many as the register budget allows)
-                const double inv = fast_rcp(dgp[rr * NK - rr * (rr - 1) / 2]);  // 1 / L[rr][rr]
+                const double inv = dgp[rr * NK - rr * (rr - 1) / 2];  // 1 / d_rr
+                LROW_DECL;
                 if (fwd) {
-                    if (has_nb) {
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= bl[k * LDP + rr] * rl(prev, k);
-                    }
+                    LROW_LOAD(DG_ROW(dgp, c));
+                    if (has_nb) v -= dot_lanes(bl + rr, LDP, prev);
 #pragma unroll
                     for (int c = 0; c < NK; ++c) {
-                        const double xc = rl(v, c) * rl(inv, c);
-                        v = (r == c) ? xc : (r > c ? v - DG_ROW(dgp, c) * xc : v);
+                        const double xc = rl(v, c);
+                        v -= LROW(c, DG_ROW(dgp, c)) * xc;
                     }
+                    v *= inv;  // z_j
                 } else {
-                    if (first_bwd) {
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * vec[mid * NK + k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) v -= bl[rr * LDP + k] * rl(prev, k);
-                    }
+                    LROW_LOAD(DG_COL(dgp, c));
+                    const double t = first_bwd ? dot_rows(bl + rr * LDP, 1, vec + mid * NK) : dot_lanes(bl + rr * LDP, 1, prev);
+                    v -= inv * t;
 #pragma unroll
                     for (int c = NK - 1; c >= 0; --c) {
-                        const double xc = rl(v, c) * rl(inv, c);
-                        v = (r == c) ? xc : (r < c ? v - DG_COL(dgp, c) * xc : v);
+                        const double xc = rl(v, c);
+                        v -= LROW(c, DG_COL(dgp, c)) * xc;
                     }
                 }
                 prev = v;
@@ -1273,6 +1350,9 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         }
         __syncthreads();
     }
+#undef LROW_DECL
+#undef LROW_LOAD
+#undef LROW
 #undef DG_ROW
 #undef DG_COL
     for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
@@ -1701,6 +1781,7 @@ __device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w)
     d.nk = b.nk, d.nj = b.nj, d.ldb = b.ldb, d.ld = b.nk + 1;
     w.Td = b.Td, w.To = b.To, w.Lf = b.Lf, w.Ek = b.Ek;
 }
+// (inlining these two was measured: 1100 VGPR spills, 31k instead of 51k agent-trajectories/s)
 __device__ __noinline__ bool factor_entry(BlkArgs b, double* lds, int* flag) {
     QpDims d;
     QpWs w;
@@ -2413,7 +2494,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
-        lds = std::max(lds, sizeof(double) * ((size_t)4 * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
+        lds = std::max(lds, sizeof(double) * ((size_t)2 * QP_STAGE_BUFS * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
         lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
         if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
             const size_t lb = (size_t)((nk + 15) & ~15);
