@@ -75,7 +75,7 @@ __host__ __device__ inline size_t polish_ws_doubles(int nj, int nk) {  // cand, 
 }
 __host__ __device__ inline int polish_lds_doubles(int nk) {
     const int pm = polish_pmax(nk);
-    return pm * (pm + 1) / 2 + 3 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
+    return pm * (pm + 1) / 2 + 3 * PL_NC + 4 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
 }
 
 namespace {
@@ -143,6 +143,7 @@ struct QpWs {
     double *rh;                     // [nslot] frozen-neighbour rows: the constant of slack = rh - n . x_a
     double *cc, *ds;                // [nslot] polish only: candidate marks / slack at the trial point
     double *cpacc;                  // [nb*oq][12]: S(6) yv(3) gz(3) per control point, ALL its rows (bounds, pairs, frozen)
+    double *pwgt;                   // [npb*oq] Newton weight of every in-batch pair row (off-diagonal blocks of the knot matrices)
     double *dx, *dxa, *cvec;        // [nb*3*oq]
     double *rbase, *rhs;            // [(M-1)*nk]
     double *Td, *To;                // [(M-1)][nk*nk], [(M-2)][nk*nk]
@@ -166,7 +167,7 @@ __host__ __device__ inline size_t ws_int_count(int N, int M, int nbmax) {
 
 __host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
-    size_t n = 7 * d.nslot_max + 12 * (size_t)nbmax * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
+    size_t n = 7 * d.nslot_max + 12 * (size_t)nbmax * d.oq + (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
                (size_t)(d.nj > 1 ? d.nj - 1 : 1) * d.ldb * d.ldb + 4 +
                2 * (size_t)nbmax * M * 3 + 3 * (size_t)(M + 1) * 9 + M + 64 + (ws_int_count(N, M, nbmax) + 1) / 2 + 2 +
@@ -186,6 +187,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.cc = p, p += dm.nslot_max;
     w.ds = p, p += dm.nslot_max;
     w.cpacc = p, p += 12 * (size_t)nbmax * d.oq;
+    w.pwgt = p, p += (size_t)(dm.npb ? dm.npb : 1) * d.oq;
     w.dx = p, p += (size_t)nbmax * 3 * d.oq;
     w.dxa = p, p += (size_t)nbmax * 3 * d.oq;
     w.cvec = p, p += (size_t)nbmax * 3 * d.oq;
@@ -534,6 +536,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             if (accum) {
                 const double sg = a_lo ? 1.0 : -1.0;  // coefficient of x_a in the row is sg * n
                 if (build) {
+                    if (a_lo) w.pwgt[(size_t)(a * nb - a * (a + 1) / 2 + (b - a - 1)) * oq + j6] = wgt;
                     S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
                     S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
                     const double zz = sg * zo, vv = sg * v;
@@ -706,8 +709,8 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds, double dreg) {
         __syncthreads();
     }
     // stage 2: work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out.
-    // Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight is recomputed from the row's (s, z) in the
-    // column of the lower agent (16 bytes per row instead of a stored 3x3)
+    // Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight was left in pwgt by the sweep (8 bytes per
+    // row, one independent load -- not a stored 3x3, not a chain of index loads)
     const int per_knot = nb * nb * 9;
     for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
         const int j = it / per_knot + 1, r = it % per_knot;
@@ -721,11 +724,8 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds, double dreg) {
                 sv = in_lds ? sym3(lds + ((size_t)a * oq + j6) * 6, k, l) : sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
             } else {
                 const int lo = a < b ? a : b, hi = a < b ? b : a, seg = j6 / 6;
-                const int wi = w.wi_of[lo * oq + j6];
-                const size_t slot = (size_t)w.tile_base[wi >> 6] + (wi & 63) + (size_t)(6 + hi - 1) * 64;  // pair (lo, hi) is row 6 + (hi - 1) of lo's column
-                const double sr = w.s[slot], zr = w.z[slot];
                 const float* nv = c.normals + (pair_index(N, d.first + lo, d.first + hi) * M + seg) * 3;
-                sv = -(zr * fast_rcp(sr + dreg * zr)) * (double)nv[k] * (double)nv[l];
+                sv = -w.pwgt[(size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6] * (double)nv[k] * (double)nv[l];
             }
             Sv[p] = sv;
         }
