@@ -697,10 +697,59 @@ __device__ inline double sym3(const double* S, int k, int l) {
     return S[a == 0 ? b : (a == 1 ? 2 + b : 5)];
 }
 
-__device__ void assemble_blocks(const RowCtx& c, double* lds, double dreg) {
+// what the assembly of a knot block needs (a by-value subset of the row context: usable from the stand-alone factor function)
+struct AsmArgs {
+    const double *cpacc, *pwgt, *Lk, *Dk;
+    const float* normals;
+    double* Td;
+    int N, M, nb, first, oq, ldb;
+};
+
+// one work item of the block assembly = (knot j, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f)
+// tile of T_j out.  r = ((a * nb + b) * 3 + k) * 3 + l.  Ssum: LDS copy of the per-control-point weight sums [nb*oq][6] or nullptr.
+// Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight was left in pwgt by the sweep (8 bytes per
+// row, one independent load -- not a stored 3x3, not a chain of index loads)
+__device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ssum, int j, int r) {
+    const int nb = A.nb, oq = A.oq, lb = A.ldb;
+    const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
+    double Sv[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const int j6 = 6 * (j - 1) + 3 + p;
+        double sv;
+        if (a == b) {
+            sv = Ssum ? sym3(Ssum + ((size_t)a * oq + j6) * 6, k, l) : sym3(A.cpacc + ((size_t)a * oq + j6) * 12, k, l);
+        } else {
+            const int lo = a < b ? a : b, hi = a < b ? b : a, seg = j6 / 6;
+            const float* nv = A.normals + (pair_index(A.N, A.first + lo, A.first + hi) * A.M + seg) * 3;
+            sv = -A.pwgt[(size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6] * (double)nv[k] * (double)nv[l];
+        }
+        Sv[p] = sv;
+    }
+    const double* L = A.Lk + 9 * j;
+    double* out = A.Td + (size_t)(j - 1) * lb * lb + (size_t)(a * 9 + k * 3) * lb + b * 9 + l * 3;
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
+            if (e == f) acc += Sv[3 + e];
+            if (a == b && k == l) acc += A.Dk[9 * j + 3 * e + f];
+            out[(size_t)e * lb + f] = acc;
+        }
+}
+
+__device__ inline AsmArgs asm_args(const RowCtx& c) {
+    return AsmArgs{c.w.cpacc, c.w.pwgt, c.w.Lk, c.w.Dk, c.normals, c.w.Td, c.d.N, c.d.M, c.d.nb, c.d.first, c.d.oq, c.d.ldb};
+}
+
+// whole-workgroup assembly of all knot blocks (tiled path; the wave path assembles block by block BEHIND the factorisation
+// chains, see twisted_factor)
+__device__ void assemble_blocks(const RowCtx& c, double* lds) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb, M = d.M, N = d.N;
+    const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
+    const AsmArgs A = asm_args(c);
     // stage 1: per (agent, control point) the 3x3 weight sum of ALL its rows (bounds, in-batch pairs, frozen neighbours) as the
     // sweep left it in cpacc, parked in LDS when it fits (every entry is read by nine (k, l) work items)
     const bool in_lds = nb * oq * 6 <= c.lds_avail;
@@ -708,39 +757,8 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds, double dreg) {
         for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) lds[it] = w.cpacc[(size_t)(it / 6) * 12 + it % 6];
         __syncthreads();
     }
-    // stage 2: work item = (knot, agent a, agent b, dim k, dim l): six 3x3-accumulator entries in, one 3x3 (e,f) tile out.
-    // Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight was left in pwgt by the sweep (8 bytes per
-    // row, one independent load -- not a stored 3x3, not a chain of index loads)
     const int per_knot = nb * nb * 9;
-    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) {
-        const int j = it / per_knot + 1, r = it % per_knot;
-        const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
-        double Sv[6];
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-            const int j6 = 6 * (j - 1) + 3 + p;
-            double sv;
-            if (a == b) {
-                sv = in_lds ? sym3(lds + ((size_t)a * oq + j6) * 6, k, l) : sym3(w.cpacc + ((size_t)a * oq + j6) * 12, k, l);
-            } else {
-                const int lo = a < b ? a : b, hi = a < b ? b : a, seg = j6 / 6;
-                const float* nv = c.normals + (pair_index(N, d.first + lo, d.first + hi) * M + seg) * 3;
-                sv = -w.pwgt[(size_t)(lo * nb - lo * (lo + 1) / 2 + (hi - lo - 1)) * oq + j6] * (double)nv[k] * (double)nv[l];
-            }
-            Sv[p] = sv;
-        }
-        const double* L = w.Lk + 9 * j;
-        double* out = w.Td + (size_t)(j - 1) * lb * lb + (size_t)(a * 9 + k * 3) * lb + b * 9 + l * 3;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
-                if (e == f) acc += Sv[3 + e];
-                if (a == b && k == l) acc += w.Dk[9 * j + 3 * e + f];
-                out[(size_t)e * lb + f] = acc;
-            }
-    }
+    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) assemble_item(A, in_lds ? lds : nullptr, it / per_knot + 1, it % per_knot);
     // the wave-register path and the LDS-resident tiled path build their coupling blocks from Ek directly
     if (d.nj > 1 && nk > 36 && 3 * lb * (lb + 2) > c.lds_avail) {
         const size_t noff = (size_t)(d.nj - 1) * lb * lb;
@@ -777,6 +795,14 @@ __device__ __forceinline__ double rl(double v, int lane) {
 //   Lf[j][1] = coupling factor produced with block j:  j < mid: B_{j+1} = T_{j+1,j} L_jj^{-T}  (rows of block j+1)
 //                                                      j > mid: C_{j-1} = T_{j-1,j} L_jj^{-T}  (rows of block j-1)
 __device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
+
+// Progress counters of the just-in-time block assembly (LDS ints behind the two chain areas): cnt[i] counts the helper waves that
+// have finished the blocks of chain step i; a chain may load its i-th block when all QP_THREADS/64 - 2 of them have.
+#define ASM_HELPERS (QP_THREADS / 64 - 2)
+__device__ __forceinline__ void wait_blocks(int* cnt, int i) {
+    while (__hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ASM_HELPERS) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // row r of the coupling block towards the next block of a chain.  T_{j+1,j}[r][k] = E_{knot j+1}[k%3][r%3] on the
 // (agent,dim) diagonal (assemble_blocks), T_{j-1,j} = T_{j,j-1}'.
@@ -987,7 +1013,7 @@ __device__ __forceinline__ void coupling_solve_lo(const QpWs& w, int j, int dir,
 }
 
 template <int NK>
-__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW) {
+__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt) {
     const int r = threadIdx.x & 63;
     const bool act = r < NK;
     const int rr = act ? r : 0;
@@ -998,6 +1024,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
         if (i > 0) syrk_tiles_lo<NK>(ldsW, r, false);
         double a[NK];
+        if (cnt) wait_blocks(cnt, i);
         const double* Tg = w.Td + (size_t)j * NK * NK;
         const double* ldsU = ldsW + 48 * SYRK_LDB;
 #pragma unroll
@@ -1027,7 +1054,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
 }
 
 template <int NK>
-__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW) {
+__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW, int* cnt, int cnt_idx) {
     const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
     const bool act = r < NK;
     const int rr = act ? r : 0;
@@ -1047,6 +1074,7 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
         nsy++;
     }
     double a[NK];
+    if (cnt) wait_blocks(cnt, cnt_idx);
     const double* Tg = w.Td + (size_t)mid * NK * NK;
     const double* ldsU = ldsW + 48 * SYRK_LDB;
 #pragma unroll
@@ -1067,7 +1095,7 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
 #else
 // one chain: blocks j0, j0+dir, ... (count of them)
 template <int NK>
-__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW) {
+__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt) {
     const int r = threadIdx.x & 63;
     const bool act = r < NK;
     const int rr = act ? r : 0;
@@ -1075,6 +1103,7 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
 #pragma unroll
     for (int k = 0; k < NK; ++k) b[k] = 0;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
+        if (cnt) wait_blocks(cnt, i);
         const double* Tg = w.Td + (size_t)j * NK * NK;
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
@@ -1105,11 +1134,12 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
 }
 
 template <int NK>
-__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW) {
+__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW, int* cnt, int cnt_idx) {
     const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
     const bool act = r < NK;
     const int rr = act ? r : 0;
     double a[NK], b[NK];
+    if (cnt) wait_blocks(cnt, cnt_idx);
     const double* Tg = w.Td + (size_t)mid * NK * NK;
 #pragma unroll
     for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
@@ -1142,23 +1172,47 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
 #endif
 
 // whole twisted factorisation; every thread of the workgroup calls it.  flag: LDS int.
+// asmb != nullptr: the knot blocks T_j are ASSEMBLED HERE, by the waves that do not run a chain, in the order the chains consume
+// them (step i: blocks i and nj-1-i; last the middle one), each step announced through an LDS counter (wait_blocks): the
+// assembly -- 8-10 % of an interior-point iteration when it was a phase of its own -- disappears behind the dependent chains.
 template <int NK>
-__device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds) {
+__device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds, const AsmArgs* asmb) {
     const int wave = threadIdx.x >> 6, mid = twist_mid(d.nj);
+    const int nl = mid, nr = d.nj - 1 - mid, SF = nl > nr ? nl : nr;
+    int* cnt = (int*)(lds + 2 * SYRK_LDS_DOUBLES);  // [SF + 1]
     if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
     bool ok = true;
     // rows >= NK of the LDS copy of B are never written: clear them once (they only feed unused tile entries)
-    for (int i = threadIdx.x; i < 2 * SYRK_LDS_DOUBLES; i += QP_THREADS) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * SYRK_LDS_DOUBLES + 64; i += QP_THREADS) lds[i] = 0.0;
     __syncthreads();
-    if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds);
-    if (wave == 1 && d.nj - 1 - mid > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, d.nj - 1 - mid, -1, lds + SYRK_LDS_DOUBLES);
+    int* cw = asmb ? cnt : nullptr;
+    if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cw);
+    if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + SYRK_LDS_DOUBLES, cw);
+    if (wave >= 2 && asmb) {
+        const AsmArgs A = *asmb;
+        const int per_knot = A.nb * A.nb * 9, ht = threadIdx.x - 128, HT = QP_THREADS - 128;
+        const int lane = threadIdx.x & 63;
+        for (int i = 0; i <= SF; ++i) {
+            if (i < SF) {
+                // first half of the helper threads: the left chain's block i; second half: the right chain's block nj-1-i
+                const int half = HT / 2, side = ht >= half, t0 = side ? ht - half : ht;
+                const int blk = side ? d.nj - 1 - i : i;
+                if (side ? i < nr : i < nl)
+                    for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it);
+            } else {
+                for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
     if (!ok && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
     __threadfence_block();
     __syncthreads();
     if (*flag) return false;
     if (wave == 0) {
-        if (!wave_factor_mid<NK>(d, w, lds) && threadIdx.x == 0) *flag = 1;
+        if (!wave_factor_mid<NK>(d, w, lds, cw, SF) && threadIdx.x == 0) *flag = 1;
     }
     __threadfence_block();
     __syncthreads();
@@ -1741,13 +1795,13 @@ __device__ void init_block_pads(const QpDims& d, const QpWs& w) {
     }
 }
 
-__device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag, int lds_avail) {
+__device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag, int lds_avail, const AsmArgs* asmb) {
     if (d.nk <= 36) {
         switch (d.nk) {
-            case 9: return twisted_factor<9>(d, w, flag, lA);
-            case 18: return twisted_factor<18>(d, w, flag, lA);
-            case 27: return twisted_factor<27>(d, w, flag, lA);
-            default: return twisted_factor<36>(d, w, flag, lA);
+            case 9: return twisted_factor<9>(d, w, flag, lA, asmb);
+            case 18: return twisted_factor<18>(d, w, flag, lA, asmb);
+            case 27: return twisted_factor<27>(d, w, flag, lA, asmb);
+            default: return twisted_factor<36>(d, w, flag, lA, asmb);
         }
     }
     return factor_tiled(d, w, flag, lA, lds_avail);
@@ -1782,11 +1836,11 @@ __device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w)
     w.Td = b.Td, w.To = b.To, w.Lf = b.Lf, w.Ek = b.Ek;
 }
 // (inlining these two was measured: 1100 VGPR spills, 31k instead of 51k agent-trajectories/s)
-__device__ __noinline__ bool factor_entry(BlkArgs b, double* lds, int* flag) {
+__device__ __noinline__ bool factor_entry(BlkArgs b, AsmArgs A, double* lds, int* flag) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    return factor_dispatch(d, w, lds, flag, b.lds_avail);
+    return factor_dispatch(d, w, lds, flag, b.lds_avail, b.nk <= 36 ? &A : nullptr);
 }
 __device__ __noinline__ void solve_entry(BlkArgs b, double* rhs, double* lds) {
     QpDims d;
@@ -2125,12 +2179,12 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             }
         }
         // ---- Newton matrix and factorisation
-        assemble_blocks(c, lds, io.dreg);
+        if (d.nk > 36) assemble_blocks(c, lds);  // wave path: assembled behind the factorisation chains (twisted_factor)
         PROF(3);
         __threadfence_block();
         __syncthreads();
         TRC(5, trc_sum(w.Td, (size_t)d.nj * d.ldb * d.ldb, red));
-        if (!factor_entry(ba, lA, flag)) {
+        if (!factor_entry(ba, asm_args(c), lA, flag)) {
             fail_reason = 2;  // Newton matrix not positive definite
             break;
         }
@@ -2495,7 +2549,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
         lds = std::max(lds, sizeof(double) * ((size_t)2 * QP_STAGE_BUFS * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
-        lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 32) + 16);
+        lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 64 + 32) + 16);  // chain areas + assembly progress counters
         if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
             const size_t lb = (size_t)((nk + 15) & ~15);
             lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
