@@ -1,0 +1,23 @@
+#!/bin/bash
+# Developer tool (GPU box): SQ activity counters of the QP kernel (one PMC pass each group; no trace domains).
+K=${1:-2000}
+OUT=$PWD/gpurun_out/pmcsq; rm -rf $OUT; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+i=0
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python $GRAFT_REPO_ROOT/bench.py --missions-per-gpu $K --steps 1 --warmup 1 --no-cpu-baseline --no-latency > $OUT/g$i.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(float); n = collections.Counter()
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "qp_batch" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(agg): print(f"{k:32s} {agg[k] / n[k]:.4g} per launch ({n[k]} launches)")
+PY
