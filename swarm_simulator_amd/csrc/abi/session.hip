@@ -185,7 +185,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
         if (grid_of[k] == k) grid_bytes += al(sizeof(float) * (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2]);
     const size_t total = grid_bytes + al(sizeof(DevWorld) * K) + 2 * al(sizeof(int) * K) + al(sizeof(float) * (size_t)K * N * P * 3) +
                          al(sizeof(double) * K * P) + 2 * al(sizeof(double) * (size_t)K * N * 9) + al(sizeof(double) * K * N) +
-                         2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) +
+                         2 * al(sizeof(double) * (size_t)K * N * 3) + al(sizeof(int) * K * N) + al(sizeof(unsigned) * (size_t)K * SFC_MASK_WORDS) +
                          al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
                          al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
                          2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
@@ -253,6 +253,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     double* radius = A.take<double>((size_t)K * N);
     double* mv = A.take<double>((size_t)K * N * 3);
     double* ma = A.take<double>((size_t)K * N * 3);
+    d.sfc_mask = A.take<unsigned>((size_t)K * SFC_MASK_WORDS);
     d.sfc_count = A.take<int>((size_t)K * N);
     d.sfc_box = A.take<double>((size_t)K * N * MB * 6);
     d.sfc_time = A.take<double>((size_t)K * N * MB);

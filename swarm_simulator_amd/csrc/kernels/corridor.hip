@@ -21,33 +21,99 @@
 
 // SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
 #define SFC_WAVES 4         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
-#define SFC_MASK_WORDS 8192  // 262144 cells = 32 KB; larger grids fall back to reading the float grid
 
 namespace {
 
 struct AxisCache {
     double lo, hi;  // extent the cached keys belong to
-    double vnext;   // the accumulated sample coordinate at which the loop of axis_keys stopped (to continue when hi grows)
     int n;          // number of samples
+    unsigned zmask; // OR of 1 << key over the samples inside the grid (the column test wants this of the z axis)
+    int zneg;       // first sample outside the grid, or -1
 };
 
 // Computes the voxel indices of the samples along one axis of `box` (rbp_corridor.hpp:47-63 for that axis):
 //   v = lo; c = 0; while (v < hi + 1e-6) { coord = (c == 0 && lo > world_min + 1e-6) ? lo - 1e-6 : v + 1e-6; ... v += res }
-// and DynamicEDTOctomap::getDistance's key computation floor((1/res_map) * (double)(float)coord) - key_min.
-// All lanes run the same scalar loop and store identical values.  (c0, v0) continue an earlier run with the same lo: the
-// accumulated coordinates are exactly those a fresh run would produce.
-__device__ __forceinline__ int axis_keys(int* keys, int cap, double lo, double hi, double step, double world_lo, double rf,
-                                         int key_min, int dim, int c0, double v0, double* vnext) {
-    int c = c0;
-    double v = v0;
-    for (; v < hi + SP_EPSILON_FLOAT && c < cap; v += step, ++c) {
+// and DynamicEDTOctomap::getDistance's key computation k(v) = floor((1/res_map) * (double)(float)coord) - key_min.
+//
+// The reference's coordinates are the partial sums of a chain of double additions -- sequential, 32 cycles per addition on
+// this machine, and a list of ~100 samples is rebuilt every time the lower end of the box moves.  Instead lane c evaluates
+// the closed form t = lo + c*res, which differs from the c-th partial sum by at most d = (c + 4) * 2^-52 * max|v| (c roundings
+// of at most half an ulp each in the chain, two in the closed form, doubled), and because k(.) and the loop test are
+// MONOTONE in v, k(t - d) == k(t + d) proves that the chain value has that key too (and t + d < lim / t - d >= lim decide
+// the loop test).  The sample coordinates sit 1e-6 away from the cell boundaries and d is ~1e-12, so this practically always
+// succeeds; if any lane cannot prove its key, the whole list is rebuilt by the chain of additions itself (axis_keys_chain).
+// Either way the keys are exactly the reference's.  c0 > 0 continues a list whose upper end grew (same lo).
+// zmask / zneg (used for the z axis): OR of 1 << key over the valid samples, index of the first sample outside the grid.
+__device__ __noinline__ int axis_keys_chain(int* keys, int cap, double lo, double hi, double step, double world_lo, double rf, int key_min,
+                                            int dim, unsigned* zmask, int* zneg) {
+    int c = 0;
+    unsigned zm = 0;
+    int zn = -1;
+    for (double v = lo; v < hi + SP_EPSILON_FLOAT && c < cap; v += step, ++c) {  // every lane runs the same loop
         double coord = v + SP_EPSILON_FLOAT;
         if (c == 0 && lo > world_lo + SP_EPSILON_FLOAT) coord = lo - SP_EPSILON_FLOAT;
-        float cf = (float)coord;  // octomap::point3d is float32
-        int k = (int)floor(rf * (double)cf) - key_min;
-        keys[c] = (k >= 0 && k < dim) ? k : -1;
+        const float cf = (float)coord;  // octomap::point3d is float32
+        const int k = (int)floor(rf * (double)cf) - key_min;
+        const bool in = k >= 0 && k < dim;
+        keys[c] = in ? k : -1;
+        if (in && k < 32) zm |= 1u << k;
+        if (!in && zn < 0) zn = c;
     }
-    *vnext = v;
+    *zmask = zm, *zneg = zn;
+    return c;
+}
+
+__device__ __forceinline__ int axis_keys(const bool WANT_Z, int* keys, int cap, double lo, double hi, double step, double world_lo,
+                                         double rf, int key_min, int dim, int c0, unsigned* zmask, int* zneg, int lane) {
+    const double lim = hi + SP_EPSILON_FLOAT;
+    const double vmax = fmax(fabs(lo), fabs(lim) + step);
+    const bool nudge_down = lo > world_lo + SP_EPSILON_FLOAT;
+    int c = c0, zn = *zneg;
+    unsigned zm = 0;
+    bool unproven = false;
+#ifndef SFC_FORCE_CHAIN  // (test builds: always take the chain, to check that both routes give the reference's keys)
+    while (c < cap) {
+        const int ci = c + lane;
+        const double t = lo + (double)ci * step;
+        const double dl = ci == 0 ? 0.0 : (double)(ci + 4) * 0x1p-52 * vmax;  // the 0-th partial sum is lo itself
+        const double ta = t - dl, tb = t + dl;
+        const bool acc = ci < cap && tb < lim;                   // certainly inside the loop
+        bool open = ci < cap && !(tb < lim) && !(ta >= lim);     // cannot tell
+        bool in = false;
+        int k = -1;
+        if (acc) {
+            const double ca = (ci == 0 && nudge_down) ? lo - SP_EPSILON_FLOAT : ta + SP_EPSILON_FLOAT;
+            const double cb = (ci == 0 && nudge_down) ? lo - SP_EPSILON_FLOAT : tb + SP_EPSILON_FLOAT;
+            const int ka = (int)floor(rf * (double)(float)ca), kb = (int)floor(rf * (double)(float)cb);
+            open = ka != kb;
+            k = ka - key_min;
+            in = k >= 0 && k < dim;
+        }
+        if (__ballot(open)) {  // (a lane beyond the end of the list is never open: the acceptance test is monotone in c)
+            unproven = true;
+            break;
+        }
+        const int nacc = __popcll(__ballot(acc));  // a prefix of the lanes
+        if (acc) {
+            keys[ci] = in ? k : -1;
+            if (WANT_Z && in && k < 32) zm |= 1u << k;
+        }
+        if (WANT_Z) {
+            const unsigned long long nb = __ballot(acc && !in);
+            if (nb && zn < 0) zn = c + __ffsll((long long)nb) - 1;
+        }
+        c += nacc;
+        if (nacc < 64) break;
+    }
+#else
+    unproven = true;
+#endif
+    if (unproven) return axis_keys_chain(keys, cap, lo, hi, step, world_lo, rf, key_min, dim, zmask, zneg);
+    if (WANT_Z) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) zm |= __shfl_xor(zm, o);
+        *zmask |= zm, *zneg = zn;
+    }
     return c;
 }
 
@@ -78,29 +144,38 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
 #endif
     int n[3];
     const int* kp[3];
+    unsigned zmask = 0;  // of the list kp[2] points at: the z cells the box touches
+    int zneg = -1;       // ... first z sample outside the grid (getDistance = -1 there): every column "hits" at that sample
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const double lo = box[a], hi = box[a + 3];
         AxisCache& f = c.cache[a];
         AxisCache& sl = c.slab[a];
+        bool slab = false;
         if (f.lo == lo && f.hi == hi) {
-            kp[a] = c.keys[a], n[a] = f.n;
         } else if (sl.lo == lo && sl.hi == hi) {
-            kp[a] = c.skeys[a], n[a] = sl.n;
-        } else if (f.lo == lo && hi > f.hi && f.n > 0) {  // upper end grew: continue the accumulation where it stopped
-            f.n = axis_keys(c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, f.vnext, &f.vnext);
-            f.hi = hi;
-            kp[a] = c.keys[a], n[a] = f.n;
+            slab = true;
+        } else if (f.lo == lo && hi > f.hi && f.n > 0) {  // upper end grew: the samples so far stay, append the new ones
+            unsigned zm = f.zmask;
+            int zn = f.zneg;
+            f.n = axis_keys(a == 2, c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, &zm, &zn, lane);
+            f.hi = hi, f.zmask = zm, f.zneg = zn;
         } else if (hi - lo < (SFC_SLAB - 3) * c.res[a]) {
-            sl.n = axis_keys(c.skeys[a], SFC_SLAB, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, lo, &sl.vnext);
-            sl.lo = lo, sl.hi = hi;
-            kp[a] = c.skeys[a], n[a] = sl.n;
+            unsigned zm = 0;
+            int zn = -1;
+            sl.n = axis_keys(a == 2, c.skeys[a], SFC_SLAB, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
+            sl.lo = lo, sl.hi = hi, sl.zmask = zm, sl.zneg = zn;
+            slab = true;
         } else {
-            f.n = axis_keys(c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, lo, &f.vnext);
-            f.lo = lo, f.hi = hi;
-            kp[a] = c.keys[a], n[a] = f.n;
+            unsigned zm = 0;
+            int zn = -1;
+            f.n = axis_keys(a == 2, c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
+            f.lo = lo, f.hi = hi, f.zmask = zm, f.zneg = zn;
         }
+        kp[a] = slab ? c.skeys[a] : c.keys[a], n[a] = slab ? sl.n : f.n;
+        if (a == 2) zmask = slab ? sl.zmask : f.zmask, zneg = slab ? sl.zneg : f.zneg;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the key lists are written by one lane each and read by all
     __builtin_amdgcn_wave_barrier();
 #ifdef SFC_PROFILE
     const long long pt1 = wall_clock64();
@@ -117,16 +192,6 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
         // number of getDistance calls the reference would have made (early exit at the first obstacle) are unchanged --
         // with n2 times fewer steps.
         const int n2 = n[2], n1 = n[1], nyz = c.dim[1] * c.dim[2], nzz = c.dim[2];
-        unsigned zmask = 0;
-        int zneg = -1;  // first z sample outside the grid (getDistance = -1 there): every column "hits" at that sample
-        for (int q = 0; q < n2; ++q) {
-            const int kz = kp[2][q];
-            if (kz < 0) {
-                if (zneg < 0) zneg = q;
-            } else {
-                zmask |= 1u << kz;
-            }
-        }
         const long long ncol = (long long)n[0] * n1;
         int c1 = lane % n1, c0 = lane / n1;
         const int d1 = 64 % n1, d0 = 64 / n1;
@@ -278,6 +343,34 @@ __device__ void expand_box(SfcCtx& c, double* box, int lane) {
     }
 }
 
+// One bit per grid cell: dist < radius - 1e-6 for the radius of the mission's first agent (agents with another radius read the
+// float grid).  Built once per mission and launch -- the 16 workgroups of a mission used to rebuild it from the 0.94 MB grid each.
+// Coalesced reads, one ballot per 64 cells; grid = (SFC_MASK_BLOCKS, K).
+#define SFC_MASK_BLOCKS 8
+__global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
+    const int mission = blockIdx.y, lane = threadIdx.x & 63;
+    const DevWorld w = s.worlds[mission];
+    const unsigned ncell = (unsigned)w.dim[0] * w.dim[1] * w.dim[2];
+    if (ncell + 64 > 32u * SFC_MASK_WORDS) return;
+    const double cmp0 = s.radius[(size_t)mission * s.N] - SP_EPSILON_FLOAT;
+    unsigned* mask = s.sfc_mask + (size_t)mission * SFC_MASK_WORDS;
+    const unsigned nchunk = (ncell + 63) >> 6, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = SFC_MASK_BLOCKS * 4;
+    for (unsigned c0 = wave; c0 < nchunk; c0 += 4 * nwave) {
+        bool occ[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned cell = (c0 + u * nwave) * 64 + lane;
+            occ[u] = cell < ncell && (double)w.dist[cell] < cmp0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned c = c0 + u * nwave;
+            const unsigned long long b = __ballot(occ[u]);
+            if (lane == 0 && c < nchunk) mask[2 * c] = (unsigned)b, mask[2 * c + 1] = (unsigned)(b >> 32);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
 #ifdef SFC_PROFILE
     const long long t_start = wall_clock64();
@@ -288,28 +381,19 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     const int M = s.Mk[mission], P = M + 1, PS = s.M + 1, MB = s.max_boxes, MBcap = s.MBk[mission];  // PS, MB: slot strides
     __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
     __shared__ int slab_all[SFC_WAVES][3][SFC_SLAB];
-    __shared__ unsigned mask[SFC_MASK_WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned mask[SFC_MASK_WORDS];
     extern __shared__ int box_log_all[];  // [SFC_WAVES][MB][P]
     int* box_log = box_log_all + (size_t)wave * MB * PS;
     const DevWorld w = s.worlds[mission];
-    // ---- occupancy bitmask of this mission's grid for the radius of the group's first agent, built once per workgroup
-    // with coalesced reads + ballots.  The SFC test only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per
-    // cell (29 KB for the 101x101x23 grid) replaces ~0.6 M float reads per agent from L2/MALL by LDS reads.
-    const int q0 = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES;
-    const double radius0 = s.radius[(size_t)mission * s.N + q0];
+    // ---- occupancy bitmask of this mission's grid (mask_kernel below; 29 KB for the 101x101x23 grid) into LDS.  The SFC test
+    // only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per cell replaces ~0.6 M float reads per agent.
+    const double radius0 = s.radius[(size_t)mission * s.N];
     const unsigned ncell = (unsigned)w.dim[0] * w.dim[1] * w.dim[2];
     const bool mask_fits = ncell + 64 <= 32u * SFC_MASK_WORDS;
     if (mask_fits) {
-        const double cmp0 = radius0 - SP_EPSILON_FLOAT;
-        for (unsigned base = wave * 64; base < ((ncell + 63) & ~63u); base += 64 * SFC_WAVES) {
-            const unsigned cell = base + lane;
-            const bool occ = cell < ncell && (double)w.dist[cell] < cmp0;
-            const unsigned long long b = __ballot(occ);
-            if (lane == 0) {
-                mask[base >> 5] = (unsigned)b;
-                mask[(base >> 5) + 1] = (unsigned)(b >> 32);
-            }
-        }
+        const uint4* gm = (const uint4*)(s.sfc_mask + (size_t)mission * SFC_MASK_WORDS);
+        const unsigned nq = (((ncell + 63) >> 6) * 2 + 2 + 3) >> 2;  // 16-byte quads; the column test reads one word past the last cell
+        for (unsigned i = threadIdx.x; i < nq; i += 64 * SFC_WAVES) ((uint4*)mask)[i] = gm[i];
     }
     __syncthreads();
     if (qi >= s.agent_end) return;
@@ -322,7 +406,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
         c.world_min[a] = s.p.world_min[a], c.world_max[a] = s.p.world_max[a];
         c.keys[a] = keys_all[wave][a];
         c.skeys[a] = slab_all[wave][a];
-        c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0, c.cache[a].vnext = 0;
+        c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0, c.cache[a].zmask = 0, c.cache[a].zneg = -1;
         c.slab[a] = c.cache[a];
     }
     c.res[0] = c.res[1] = s.p.box_xy_res, c.res[2] = s.p.box_z_res;
@@ -503,6 +587,7 @@ void launch_corridor(const DevSession& s, hipStream_t st) {
     const size_t lds = sizeof(int) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1);
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
     (void)hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (groups > 0) hipLaunchKernelGGL(mask_kernel, dim3(SFC_MASK_BLOCKS, s.K), dim3(256), 0, st, s);
     if (groups > 0) hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
     const long long total = (long long)s.K * s.npair * s.M;
     if (total > 0) hipLaunchKernelGGL(rsfc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s);

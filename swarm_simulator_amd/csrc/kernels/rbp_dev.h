@@ -23,6 +23,7 @@
 #define QP_MAX_NB 64           /* widest batch (agents) one workgroup factorises: nk = 9 * 64 = 576 */
 inline int planner_max_batch() { return QP_MAX_NB; }
 #define SFC_MAXS 512           /* sfc_kernel: max samples per axis (world extent / box resolution + 3); checked at session create */
+#define SFC_MASK_WORDS 8192    /* occupancy bitmask of a grid: 262144 cells = 32 KB; larger grids are read as floats */
 
 struct DevWorld {
     int dim[3];
@@ -53,6 +54,7 @@ struct DevSession {
     const double* radius;     // [K][N]
     const double* max_vel;    // [K][N][3]
     const double* max_acc;    // [K][N][3]
+    unsigned* sfc_mask;       // [K][SFC_MASK_WORDS] bit = dist < radius(agent 0) - 1e-6, written by mask_kernel, read by sfc_kernel
     int* sfc_count;           // [K][N]
     double* sfc_box;          // [K][N][MB][6]
     double* sfc_time;         // [K][N][MB]

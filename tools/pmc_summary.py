@@ -13,7 +13,7 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        k = "qp_batch_kernel" if "qp_batch" in n else "sfc_kernel" if "sfc_kernel" in n else "rsfc_kernel" if "rsfc" in n else None
+        k = "qp_batch_kernel" if "qp_batch" in n else "rsfc_kernel" if "rsfc_kernel" in n else "sfc_kernel" if "sfc_kernel" in n else None
         if k is None:
             continue
         agg[k][0] += 1

@@ -14,7 +14,7 @@ s.run(); st = s.download()
 sc = s.scalars()
 names = ["polish (+tail)", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "batch setup", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
 tot = sc[:, 8:20].sum(1)
-print("status", st, "iters", sc[:, 2])
+print("missions", len(st), "failed", int(np.count_nonzero(st)), "IPM iterations per mission", sc[:, 2].mean())
 for i, n in enumerate(names):
     print(f"{n:18s} {sc[:, 8 + i].mean() / 1e8 * 1e3:9.2f} ms (100 MHz clock)  {100 * sc[:, 8 + i].sum() / tot.sum():5.1f} %")
 print("total", tot.mean() / 1e8 * 1e3, "ms per mission")
