@@ -11,7 +11,7 @@ NA = int(os.environ.get("AGENTS", "64"))
 m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), NA, p)
 s = planner.Session(worlds, [m] * K, p, plans)
 s.run(); st = s.download()
-sc = s.scalars()
+sc = s.scalars(28)
 names = ["polish (+tail)", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "batch setup", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
 tot = sc[:, 8:20].sum(1)
 print("missions", len(st), "failed", int(np.count_nonzero(st)), "IPM iterations per mission", sc[:, 2].mean())
@@ -20,3 +20,5 @@ for i, n in enumerate(names):
 print("total", tot.mean() / 1e8 * 1e3, "ms per mission")
 for i, n in enumerate(["polish: candidates+K0+gradient", "polish: V columns + S", "polish: dual active-set (wave 0)", "polish: primal step/verify"]):
     print(f"  {n:34s} {sc[:, 20 + i].mean() / 1e8 * 1e3:9.2f} ms")
+if os.environ.get("LHSTATS"):
+    print(f"  LH calls {sc[:, 27].mean():.1f}  appends {sc[:, 25].mean():.1f}  gradient passes {sc[:, 24].mean():.1f} (slot shared with the byte counter: subtract it)  inner solves {sc[:, 26].mean():.1f} per mission")
