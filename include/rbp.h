@@ -203,6 +203,17 @@ int rbp_session_create_in(rbp_ctx* ctx, rbp_session** out, int K, const rbp_worl
 
 /* library/version/diagnostics */
 const char* rbp_version(void);
+/* ---- distance grid of a world on the GPU ---------------------------------
+ * What  DynamicEDTOctomap distmap(max_dist, tree, bbx_min, bbx_max, false); distmap.update();  followed by getDistance() on every
+ * voxel centre of the box yields (swarm_traj_planner_rbp_test_all.cpp:57-63, swarm_traj_planner_rbp.cpp:73-80): the float grid
+ * rbp_world.dist points at, [nx][ny][nz] with z fastest, clamped at ((int)(max_dist / res + 1)) cells like dynamicEDT3D.
+ * leaf_keys: [n_leaves][4] = min-corner voxel key minus 32768 (x, y, z) and edge length in voxels of every occupied leaf (what
+ * rbp_octomap_load_bt of rbp_host.h returns).  rbp_edt_dims gives the grid shape (dim, key_min as in rbp_world) for a box;
+ * rbp_edt_build fills dist (host buffer of dim[0]*dim[1]*dim[2] floats).  Bit-identical to the host library's rbp_world_build. */
+int rbp_edt_dims(double res, const double bbx_min[3], const double bbx_max[3], int32_t dim[3], int32_t key_min[3]);
+int rbp_edt_build(const int32_t* leaf_keys, int64_t n_leaves, double res, const double bbx_min[3], const double bbx_max[3],
+                  double max_dist, float* dist);
+
 const char* rbp_last_error(void);
 int rbp_device_count(void);
 

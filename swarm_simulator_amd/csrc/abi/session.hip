@@ -51,6 +51,8 @@ void repack_boxes(T* dst, int dst_mb, const T* src, int src_mb, int N, int w) {
 
 }  // namespace
 
+int rbp_set_error(int code, const char* msg) { return fail(code, msg); }  // for the other translation units (kernels/edt.hip)
+
 // A context owns one device arena that successive sessions (and the synchronous one-shot calls) reuse: the drop-in calls
 // rbp_corridor_update / rbp_planner_update would otherwise hipMalloc + hipFree ~10 MB per plan.
 struct rbp_ctx {

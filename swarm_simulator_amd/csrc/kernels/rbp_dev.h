@@ -74,6 +74,8 @@ enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3,
        SC_N = 28 };
 enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
+int rbp_set_error(int code, const char* msg);  // abi/session.hip: records the message rbp_last_error() returns, returns code
+
 // launchers (defined in the .hip files)
 void launch_corridor(const DevSession& s, hipStream_t st);
 // kernels/qp.hip is built twice: _w2 = 256 VGPRs, one workgroup per CU; _w4 = 128 VGPRs, two workgroups per CU

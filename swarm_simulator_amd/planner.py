@@ -59,6 +59,8 @@ def lib():
         L.rbp_session_scalars.argtypes = [C.c_void_p, A.c_double_p, C.c_int, C.c_void_p]
         L.rbp_session_destroy.argtypes = [C.c_void_p]
         L.rbp_session_destroy.restype = None
+        L.rbp_edt_dims.argtypes = [C.c_double, C.c_double * 3, C.c_double * 3, C.c_int32 * 3, C.c_int32 * 3]
+        L.rbp_edt_build.argtypes = [A.c_int32_p, C.c_int64, C.c_double, C.c_double * 3, C.c_double * 3, C.c_double, A.c_float_p]
         L.rbp_ctx_create.argtypes = [P(C.c_void_p), C.c_int]
         L.rbp_ctx_destroy.argtypes = [C.c_void_p]
         L.rbp_ctx_destroy.restype = None
@@ -79,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "rbp_last_error", "rbp_device_count",
     "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
     "rbp_session_create_in",
+    "rbp_edt_dims", "rbp_edt_build",
 ]
 
 
@@ -227,3 +230,22 @@ class Session:
             self.close()
         except Exception:
             pass
+
+
+def build_world(keys, res, param: Param, max_dist=1.0):
+    """The distance grid of a world ON THE GPU (rbp_edt_build): DynamicEDTOctomap(maxDist, tree, world_min, world_max, false).update()
+    (swarm_traj_planner_rbp_test_all.cpp:57-63) + getDistance on every voxel centre.  Same result, bit for bit, as host.build_world."""
+    import numpy as np
+    from .types import World
+    keys = np.ascontiguousarray(keys, np.int32).reshape(-1, 4)
+    lo = (C.c_double * 3)(param.world_x_min, param.world_y_min, param.world_z_min)
+    hi = (C.c_double * 3)(param.world_x_max, param.world_y_max, param.world_z_max)
+    dim, kmin = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    rc = lib().rbp_edt_dims(res, lo, hi, dim, kmin)
+    if rc:
+        raise ValueError(f"rbp_edt_dims rc={rc}: {last_error()}")
+    dist = np.zeros(tuple(dim), np.float32)
+    rc = lib().rbp_edt_build(A.ptr(keys, A.c_int32_p), len(keys), res, lo, hi, max_dist, A.ptr(dist, A.c_float_p))
+    if rc:
+        raise RuntimeError(f"rbp_edt_build rc={rc}: {last_error()}")
+    return World(dist, tuple(kmin), res)

@@ -64,6 +64,10 @@ def test_product_has_no_cpu_fallback():
     pl = planner.RBPPlanner(c.mission, c.param)
     assert pl.update(False, c.with_corridor()) is False and pl.rc == A.RBP_ERR_NO_DEVICE
     assert np.all(pr.sfc_count == 0)  # nothing was computed
+    from swarm_simulator_amd import host
+    keys, res, _ = host.load_octomap("empty.bt")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # the GPU distance grid (rbp_edt_build) neither
+        planner.build_world(keys, res, c.param)
 
 
 def test_product_does_not_import_the_oracle():
