@@ -217,6 +217,16 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     DevSession& d = s->d;
     d.K = K, d.N = N, d.M = M, d.max_boxes = MB, d.npair = npair;
     d.agent_begin = 0, d.agent_end = N;
+    for (int a = 0; a < 3; ++a) {
+        const double bres = a < 2 ? param->box_xy_res : param->box_z_res;
+        d.sfc_cap[a] = std::min(SFC_MAXS, (int)std::ceil((param->world_max[a] - param->world_min[a]) / bres) + 4);
+    }
+    d.sfc_mask_words = 0;
+    for (int k = 0; k < K; ++k) {
+        const size_t nc = (size_t)worlds[k].dim[0] * worlds[k].dim[1] * worlds[k].dim[2];
+        const size_t words = ((((nc + 63) >> 6) * 2 + 2) + 3) & ~size_t(3);
+        if (words <= SFC_MASK_WORDS) d.sfc_mask_words = std::max(d.sfc_mask_words, (int)words);
+    }
     for (int a = 0; a < 3; ++a) d.p.world_min[a] = param->world_min[a], d.p.world_max[a] = param->world_max[a];
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;

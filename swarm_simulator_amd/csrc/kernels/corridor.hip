@@ -21,6 +21,8 @@
 
 // SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
 #define SFC_WAVES 4         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
+typedef short sfc_key_t;             // a voxel index along one axis (< 4096), -1 outside the grid
+typedef unsigned short sfc_log_t;    // box_log entries: a run length of waypoints (<= M + 1)
 
 namespace {
 
@@ -44,7 +46,7 @@ struct AxisCache {
 // succeeds; if any lane cannot prove its key, the whole list is rebuilt by the chain of additions itself (axis_keys_chain).
 // Either way the keys are exactly the reference's.  c0 > 0 continues a list whose upper end grew (same lo).
 // zmask / zneg (used for the z axis): OR of 1 << key over the valid samples, index of the first sample outside the grid.
-__device__ __noinline__ int axis_keys_chain(int* keys, int cap, double lo, double hi, double step, double world_lo, double rf, int key_min,
+__device__ __noinline__ int axis_keys_chain(sfc_key_t* keys, int cap, double lo, double hi, double step, double world_lo, double rf, int key_min,
                                             int dim, unsigned* zmask, int* zneg) {
     int c = 0;
     unsigned zm = 0;
@@ -55,7 +57,7 @@ __device__ __noinline__ int axis_keys_chain(int* keys, int cap, double lo, doubl
         const float cf = (float)coord;  // octomap::point3d is float32
         const int k = (int)floor(rf * (double)cf) - key_min;
         const bool in = k >= 0 && k < dim;
-        keys[c] = in ? k : -1;
+        keys[c] = (sfc_key_t)(in ? k : -1);
         if (in && k < 32) zm |= 1u << k;
         if (!in && zn < 0) zn = c;
     }
@@ -63,7 +65,7 @@ __device__ __noinline__ int axis_keys_chain(int* keys, int cap, double lo, doubl
     return c;
 }
 
-__device__ __forceinline__ int axis_keys(const bool WANT_Z, int* keys, int cap, double lo, double hi, double step, double world_lo,
+__device__ __forceinline__ int axis_keys(const bool WANT_Z, sfc_key_t* keys, int cap, double lo, double hi, double step, double world_lo,
                                          double rf, int key_min, int dim, int c0, unsigned* zmask, int* zneg, int lane) {
     const double lim = hi + SP_EPSILON_FLOAT;
     const double vmax = fmax(fabs(lo), fabs(lim) + step);
@@ -95,7 +97,7 @@ __device__ __forceinline__ int axis_keys(const bool WANT_Z, int* keys, int cap, 
         }
         const int nacc = __popcll(__ballot(acc));  // a prefix of the lanes
         if (acc) {
-            keys[ci] = in ? k : -1;
+            keys[ci] = (sfc_key_t)(in ? k : -1);
             if (WANT_Z && in && k < 32) zm |= 1u << k;
         }
         if (WANT_Z) {
@@ -125,8 +127,9 @@ struct SfcCtx {
     int dim[3], key_min[3];
     double rf, world_min[3], world_max[3], res[3];
     double margin_cmp;  // margin - 1e-6
-    int* keys[3];       // LDS, full extent of the box along each axis
-    int* skeys[3];      // LDS, the short axis of the slab under test
+    sfc_key_t* keys[3];   // LDS, full extent of the box along each axis
+    sfc_key_t* skeys[3];  // LDS, the short axis of the slab under test
+    int cap[3];           // capacity of keys[a]
     AxisCache cache[3], slab[3];
     unsigned long long samples;
 #ifdef SFC_PROFILE
@@ -143,7 +146,7 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
     const long long pt0 = wall_clock64();
 #endif
     int n[3];
-    const int* kp[3];
+    const sfc_key_t* kp[3];
     unsigned zmask = 0;  // of the list kp[2] points at: the z cells the box touches
     int zneg = -1;       // ... first z sample outside the grid (getDistance = -1 there): every column "hits" at that sample
 #pragma unroll
@@ -158,7 +161,7 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
         } else if (f.lo == lo && hi > f.hi && f.n > 0) {  // upper end grew: the samples so far stay, append the new ones
             unsigned zm = f.zmask;
             int zn = f.zneg;
-            f.n = axis_keys(a == 2, c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, &zm, &zn, lane);
+            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, &zm, &zn, lane);
             f.hi = hi, f.zmask = zm, f.zneg = zn;
         } else if (hi - lo < (SFC_SLAB - 3) * c.res[a]) {
             unsigned zm = 0;
@@ -169,7 +172,7 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
         } else {
             unsigned zm = 0;
             int zn = -1;
-            f.n = axis_keys(a == 2, c.keys[a], SFC_MAXS, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
+            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
             f.lo = lo, f.hi = hi, f.zmask = zm, f.zneg = zn;
         }
         kp[a] = slab ? c.skeys[a] : c.keys[a], n[a] = slab ? sl.n : f.n;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
     }
 }
 
-__global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
+__global__ __launch_bounds__(64 * SFC_WAVES, 3) void sfc_kernel(DevSession s) {
 #ifdef SFC_PROFILE
     const long long t_start = wall_clock64();
 #endif
@@ -379,20 +382,21 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
     const int M = s.Mk[mission], P = M + 1, PS = s.M + 1, MB = s.max_boxes, MBcap = s.MBk[mission];  // PS, MB: slot strides
-    __shared__ int keys_all[SFC_WAVES][3][SFC_MAXS];
-    __shared__ int slab_all[SFC_WAVES][3][SFC_SLAB];
-    __shared__ __attribute__((aligned(16))) unsigned mask[SFC_MASK_WORDS];
-    extern __shared__ int box_log_all[];  // [SFC_WAVES][MB][P]
-    int* box_log = box_log_all + (size_t)wave * MB * PS;
+    // LDS: [occupancy mask: s.sfc_mask_words words][per wave: key lists x | y | z, three slab lists][per wave: box_log [MB][P]]
+    extern __shared__ __attribute__((aligned(16))) unsigned sfc_lds[];
+    unsigned* mask = sfc_lds;
+    const int kw = (s.sfc_cap[0] + s.sfc_cap[1] + s.sfc_cap[2] + 3 * SFC_SLAB + 1) & ~1;
+    sfc_key_t* kbase = (sfc_key_t*)(sfc_lds + s.sfc_mask_words) + (size_t)wave * kw;
+    sfc_log_t* box_log = (sfc_log_t*)((sfc_key_t*)(sfc_lds + s.sfc_mask_words) + (size_t)SFC_WAVES * kw) + (size_t)wave * MB * PS;
     const DevWorld w = s.worlds[mission];
     // ---- occupancy bitmask of this mission's grid (mask_kernel below; 29 KB for the 101x101x23 grid) into LDS.  The SFC test
     // only needs "dist < r - 1e-6" (rbp_corridor.hpp:67), so one bit per cell replaces ~0.6 M float reads per agent.
     const double radius0 = s.radius[(size_t)mission * s.N];
     const unsigned ncell = (unsigned)w.dim[0] * w.dim[1] * w.dim[2];
-    const bool mask_fits = ncell + 64 <= 32u * SFC_MASK_WORDS;
+    const unsigned nq = (((ncell + 63) >> 6) * 2 + 2 + 3) >> 2;  // 16-byte quads; the column test reads one word past the last cell
+    const bool mask_fits = 4 * nq <= (unsigned)s.sfc_mask_words;
     if (mask_fits) {
         const uint4* gm = (const uint4*)(s.sfc_mask + (size_t)mission * SFC_MASK_WORDS);
-        const unsigned nq = (((ncell + 63) >> 6) * 2 + 2 + 3) >> 2;  // 16-byte quads; the column test reads one word past the last cell
         for (unsigned i = threadIdx.x; i < nq; i += 64 * SFC_WAVES) ((uint4*)mask)[i] = gm[i];
     }
     __syncthreads();
@@ -404,8 +408,9 @@ __global__ __launch_bounds__(64 * SFC_WAVES) void sfc_kernel(DevSession s) {
     for (int a = 0; a < 3; ++a) {
         c.dim[a] = w.dim[a], c.key_min[a] = w.key_min[a];
         c.world_min[a] = s.p.world_min[a], c.world_max[a] = s.p.world_max[a];
-        c.keys[a] = keys_all[wave][a];
-        c.skeys[a] = slab_all[wave][a];
+        c.keys[a] = kbase + (a == 0 ? 0 : a == 1 ? s.sfc_cap[0] : s.sfc_cap[0] + s.sfc_cap[1]);
+        c.skeys[a] = kbase + s.sfc_cap[0] + s.sfc_cap[1] + s.sfc_cap[2] + a * SFC_SLAB;
+        c.cap[a] = s.sfc_cap[a];
         c.cache[a].lo = 1e300, c.cache[a].hi = -1e300, c.cache[a].n = 0, c.cache[a].zmask = 0, c.cache[a].zneg = -1;
         c.slab[a] = c.cache[a];
     }
@@ -584,7 +589,9 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
 void launch_corridor(const DevSession& s, hipStream_t st) {
     // updateObsBox() && updateRelBox() (:25): RSFC results are only meaningful if SFC succeeded; status keeps the
     // first error, with SFC errors taking precedence because sfc_kernel is enqueued first.
-    const size_t lds = sizeof(int) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1);
+    const int kw = (s.sfc_cap[0] + s.sfc_cap[1] + s.sfc_cap[2] + 3 * SFC_SLAB + 1) & ~1;
+    const size_t lds = sizeof(unsigned) * s.sfc_mask_words + sizeof(sfc_key_t) * (size_t)SFC_WAVES * kw +
+                       sizeof(sfc_log_t) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1) + 16;
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
     (void)hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (groups > 0) hipLaunchKernelGGL(mask_kernel, dim3(SFC_MASK_BLOCKS, s.K), dim3(256), 0, st, s);

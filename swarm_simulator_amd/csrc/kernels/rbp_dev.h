@@ -44,6 +44,8 @@ struct DevSession {
     int K, N, M, max_boxes, npair;  // M, max_boxes: session maxima = slot strides; per-mission values in Mk / MBk
     const int* Mk;            // [K] segments of mission k (<= M)
     const int* MBk;           // [K] box capacity of mission k (<= max_boxes): plan.max_boxes of the caller
+    int sfc_cap[3];           // sfc_kernel: capacity of the per-axis key lists = world extent / box resolution + 4 (<= SFC_MAXS)
+    int sfc_mask_words;       // sfc_kernel: words of LDS reserved for the occupancy mask (largest grid of the session that fits, multiple of 4)
     int agent_begin, agent_end;  // corridor stage only: agents (and pair rows i) of this shard, [0, N) when not sharded
     DevParam p;
     const DevWorld* worlds;   // [K]
