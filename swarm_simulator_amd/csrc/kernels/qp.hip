@@ -712,9 +712,13 @@ struct AsmArgs {
 // tile of T_j out.  r = ((a * nb + b) * 3 + k) * 3 + l.  Ssum: LDS copy of the per-control-point weight sums [nb*oq][6] or nullptr.
 // Off-diagonal (a != b) blocks carry -wgt n n' of the pair row (a, b): the weight was left in pwgt by the sweep (8 bytes per
 // row, one independent load -- not a stored 3x3, not a chain of index loads)
-__device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ssum, int j, int r) {
+// lower_only (wave path): lane r of a factor chain loads T[k][r] for every k but only ever uses k <= r (T is symmetric, ldl_rows works
+// on the lower triangle), so the other half is neither computed nor written: half of the assembly work and of T's write traffic.  (The
+// chain still LOADS whole rows: predicating its 36 loads and stores costs the dependent chain more than the bytes are worth, measured.)
+__device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ssum, int j, int r, bool lower_only = false) {
     const int nb = A.nb, oq = A.oq, lb = A.ldb;
     const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
+    if (lower_only && (a > b || (a == b && k > l))) return;
     double Sv[6];
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
@@ -738,7 +742,7 @@ __device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ss
             double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
             if (e == f) acc += Sv[3 + e];
             if (a == b && k == l) acc += A.Dk[9 * j + 3 * e + f];
-            out[(size_t)e * lb + f] = acc;
+            if (!(lower_only && a == b && k == l && e > f)) out[(size_t)e * lb + f] = acc;
         }
 }
 
@@ -1207,9 +1211,9 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
                 const int half = HT / 2, side = ht >= half, t0 = side ? ht - half : ht;
                 const int blk = side ? d.nj - 1 - i : i;
                 if (side ? i < nr : i < nl)
-                    for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it);
+                    for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it, true);
             } else {
-                for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it);
+                for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it, true);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1271,7 +1275,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int it = base + u * nt;
-                tmp[u] = it < NK * NK ? src[it] : 0.0;
+                tmp[u] = it < NK * NK && it % NK >= it / NK ? src[it] : 0.0;  // the upper triangle (zeros) is not fetched
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -2111,8 +2115,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     // sweeps read (s, z) three times and write them once (64 B), frozen rows also read their constant three times (+24 B); per free
     // control point the accumulators are written twice and read four times (288 B); the knot blocks are written and read once
     // (T_j), the two factor blocks per knot written once and read by both substitutions: 8 block transfers of ldb^2 doubles per knot
+    // on the tiled path; on the wave path T_j is written and the diagonal factor is read (twice) as a triangle: 5 full blocks + 3 triangles
+    const double blk_doubles = d.nk <= 36 ? 5.0 * d.nk * d.nk + 3.0 * (d.nk * (d.nk + 1) / 2) : 8.0 * d.ldb * d.ldb;
     const double bytes_iter = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6) +
-                              64.0 * (double)d.nj * d.ldb * d.ldb;
+                              8.0 * (double)d.nj * blk_doubles;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
     pw.V = w.polish + PL_NC * 14;
