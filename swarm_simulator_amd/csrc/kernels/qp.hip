@@ -9,12 +9,13 @@
 // inequality row (SFC bound :626-635, RSFC :638-684) touches exactly one knot, and the Newton matrix of a
 // primal-dual interior-point method, F'(2Q)F + J' W J, is block tridiagonal over the M-1 knots with dense
 // blocks of order nk = 9 * (batch agents).  One workgroup runs one mission's whole batch schedule in one launch:
-//   * three row sweeps per interior-point iteration stream the row state (s, z, ds, dz) from HBM/L2, coalesced along
-//     the control-point index (affine sweep incl. both parts of the corrector rhs; step sweep; speculative
-//     step + neighbourhood test + next iteration's weights);
-//   * per-control-point 3x3 accumulators are expanded into the knot blocks (no atomics);
-//   * the block-tridiagonal Cholesky: nk <= 36 twisted two-wave chains with one block row per lane in VGPRs and MFMA
-//     rank-k updates; wider batches an MFMA-tiled path (LDS-resident for nk <= 72);
+//   * three row sweeps per interior-point iteration stream the row state -- (s, z) only, in sliced-ELLPACK order: one coalesced
+//     512-byte access per wavefront and array, see QpWs -- from HBM (affine sweep incl. both parts of the corrector rhs; step
+//     sweep; step into the ping-pong arrays + neighbourhood test + next iteration's weights);
+//   * per-control-point 3x3 accumulators are expanded into the knot blocks (no atomics) by the six waves that would otherwise
+//     idle behind the factorisation chains, block by block just ahead of them (twisted_factor);
+//   * the block-tridiagonal factorisation: nk <= 36 twisted two-wave chains, L D L' with a unit factor, one block row per lane in
+//     VGPRs and MFMA rank-k updates; wider batches an MFMA-tiled path (LDS-resident for nk <= 72);
 //   * an active-set polish (qp_polish.inc) turns the interior-point answer into the exact optimum, verified by a full
 //     KKT check; from the second Gauss-Seidel pass on it is tried before any interior-point iteration.
 // Batches of a mission are solved strictly in the reference's order (Gauss-Seidel, :140-148); parallelism comes
