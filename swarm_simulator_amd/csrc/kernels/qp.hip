@@ -44,6 +44,12 @@
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
+#ifndef QP_SIGMA_POW
+#define QP_SIGMA_POW 3  // Mehrotra's centring exponent
+#endif
+#ifndef QP_NBHD_GAMMA
+#define QP_NBHD_GAMMA 1e-3  // wide neighbourhood: no complementarity product below gamma * mu
+#endif
 #ifndef QP_STEP_FRAC
 #define QP_STEP_FRAC 0.997  // fraction of the step to the boundary (A/B on one box: 0.98 +5 %, 0.99 +1.4 %, 0.997 and 0.999 best, 0.9999 +20 % time)
 #endif
@@ -2233,7 +2239,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows_free;
         TRC(9, a_aff); TRC(10, mu_aff);
         double sigma = mu_aff / mu;
-        sigma = sigma * sigma * sigma;
+        sigma = QP_SIGMA_POW == 2 ? sigma * sigma : (QP_SIGMA_POW == 4 ? sigma * sigma * sigma * sigma : sigma * sigma * sigma);
         io.sigma_mu = sigma * mu;
         // ---- corrector (its right-hand side was accumulated by the AFF sweep in two parts)
         __threadfence_block();
@@ -2281,7 +2287,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             rows_swept += nrows_free;
             __threadfence_block();
             __syncthreads();
-            if (pmin >= 1e-3 * gap_next / nrows_free) break;
+            if (pmin >= QP_NBHD_GAMMA * gap_next / nrows_free) break;
             alpha *= 0.8;
         }
         // the new state becomes the current one
