@@ -44,6 +44,10 @@
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
+#ifndef QP_ROW_UNROLL
+#define QP_ROW_UNROLL (QP_WAVES_PER_EU >= 4 ? 1 : 2)  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box, planner time of
+                                                    // the 128-VGPR build: 1: 2094, 2: 2116, 3: 2135, 4: 2172, 8: 2165 ms; single mission (256 VGPRs): 2 is best
+#endif
 #ifndef QP_SIGMA_POW
 #define QP_SIGMA_POW 3  // Mehrotra's centring exponent
 #endif
@@ -567,7 +571,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         const int cnt = w.fcnt[grp];
         const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
         const size_t r0 = base + (size_t)d.ncol0 * 64;
-#pragma unroll 4
+#pragma unroll QP_ROW_UNROLL
         for (int idx = 0; idx < cnt; ++idx) {
             const size_t r = r0 + (size_t)idx * 64;
             const double n0 = nr[3 * idx], n1 = nr[3 * idx + 1], n2 = nr[3 * idx + 2];

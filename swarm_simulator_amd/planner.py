@@ -59,8 +59,12 @@ def lib():
         L.rbp_session_scalars.argtypes = [C.c_void_p, A.c_double_p, C.c_int, C.c_void_p]
         L.rbp_session_destroy.argtypes = [C.c_void_p]
         L.rbp_session_destroy.restype = None
-        L.rbp_edt_dims.argtypes = [C.c_double, C.c_double * 3, C.c_double * 3, C.c_int32 * 3, C.c_int32 * 3]
-        L.rbp_edt_build.argtypes = [A.c_int32_p, C.c_int64, C.c_double, C.c_double * 3, C.c_double * 3, C.c_double, A.c_float_p]
+        try:  # (developer A/B builds of older commits loaded through RBP_HIP_LIB may predate the GPU distance grid)
+            L.rbp_edt_dims.argtypes = [C.c_double, C.c_double * 3, C.c_double * 3, C.c_int32 * 3, C.c_int32 * 3]
+            L.rbp_edt_build.argtypes = [A.c_int32_p, C.c_int64, C.c_double, C.c_double * 3, C.c_double * 3, C.c_double, A.c_float_p]
+        except AttributeError:
+            if not os.environ.get("RBP_HIP_LIB"):
+                raise
         L.rbp_ctx_create.argtypes = [P(C.c_void_p), C.c_int]
         L.rbp_ctx_destroy.argtypes = [C.c_void_p]
         L.rbp_ctx_destroy.restype = None
