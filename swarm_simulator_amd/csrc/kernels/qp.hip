@@ -44,6 +44,9 @@
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
+#ifndef QP_STAGE_LOADS
+#define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
+#endif
 #ifndef QP_ROW_UNROLL
 #define QP_ROW_UNROLL (QP_WAVES_PER_EU >= 4 ? 1 : 2)  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box, planner time of
                                                     // the 128-VGPR build: 1: 2094, 2: 2116, 3: 2135, 4: 2172, 8: 2165 ms; single mission (256 VGPRs): 2 is best
@@ -1252,7 +1255,10 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
 // A stage holds, per chain, the diagonal factor PACKED (lower triangle, column-major: element (r,k), r >= k, at
 // k*NK - k(k-1)/2 + r - k) and the full coupling block (element (r,k) at k*(NK+1) + r): 2 x (2*DG + 2*BLK) + nj*NK
 // doubles = 74 KB for NK = 36, so that two 256-thread workgroups share one CU's LDS.
-template <int NK>
+// ROLE: 0 = compiled for the two chain waves, 1 = for the staging waves (2..), -1 = for all (one function).  The two roles are
+// separate __noinline__ functions (solve_entry): the staging waves need a dozen registers, and a function that uses only caller-saved
+// VGPRs has no prologue -- six of the eight waves stop writing 48 callee-saved registers to scratch and reading them back per call.
+template <int NK, int ROLE>
 __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
     constexpr int LDP = NK + 1, BLK = NK * LDP, DG = (NK * (NK + 1) / 2 + 7) & ~7, STG = 2 * DG + 2 * BLK;
     // stage layout: [0, DG) left diag, [DG, DG+BLK) left coupling, [DG+BLK, 2DG+BLK) right diag, [2DG+BLK, STG) right coupling
@@ -1269,30 +1275,30 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
     auto right_j = [&](int s) { return s < SF ? (s - (SF - nr) >= 0 ? nj - 1 - (s - (SF - nr)) : -1) : (s == SF ? -1 : (mid + 1 + (s - SF - 1) <= nj - 1 ? mid + 1 + (s - SF - 1) : -1)); };
     auto copy_blk = [&](const double* src, double* dst, int t0, int nt) {
-        // all loads first, then the LDS stores (element (r,k) stays at k*LDP + r): keeps up to 8 loads in flight per lane
-        double tmp[8];
+        // all loads first, then the LDS stores (element (r,k) stays at k*LDP + r): keeps up to QP_STAGE_LOADS loads in flight per lane
+        double tmp[QP_STAGE_LOADS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < QP_STAGE_LOADS; ++u) {
             const int it = t0 + u * nt;
             tmp[u] = it < NK * NK ? src[it] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < QP_STAGE_LOADS; ++u) {
             const int it = t0 + u * nt;
             if (it < NK * NK) dst[(it / NK) * LDP + it % NK] = tmp[u];
         }
-        for (int it = t0 + 8 * nt; it < NK * NK; it += nt) dst[(it / NK) * LDP + it % NK] = src[it];
+        for (int it = t0 + QP_STAGE_LOADS * nt; it < NK * NK; it += nt) dst[(it / NK) * LDP + it % NK] = src[it];
     };
     auto copy_diag = [&](const double* src, double* dst, int t0, int nt) {  // lower triangle of src[k*NK + r] -> packed
-        for (int base = t0; base < NK * NK; base += 8 * nt) {  // eight loads in flight per lane, then the LDS stores
-            double tmp[8];
+        for (int base = t0; base < NK * NK; base += QP_STAGE_LOADS * nt) {  // QP_STAGE_LOADS loads in flight per lane, then the LDS stores
+            double tmp[QP_STAGE_LOADS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < QP_STAGE_LOADS; ++u) {
                 const int it = base + u * nt;
                 tmp[u] = it < NK * NK && it % NK >= it / NK ? src[it] : 0.0;  // the upper triangle (zeros) is not fetched
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < QP_STAGE_LOADS; ++u) {
                 const int it = base + u * nt, k = it / NK, r = it % NK;
                 if (it < NK * NK && r >= k) dst[k * NK - k * (k - 1) / 2 + r - k] = tmp[u];
             }
@@ -1320,7 +1326,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     };
     for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG, tid, QP_THREADS);
     __syncthreads();
-    const int wave = tid >> 6, r = tid & 63;
+    const int wave = ROLE == 0 ? (tid >> 6) & 1 : (ROLE == 1 ? 2 : tid >> 6), r = tid & 63;  // (role 1 only needs "wave >= 2")
     const int rr = r < NK ? r : 0;
     // row rr of the packed factor: a[k] = L[rr][k], k <= rr; column rr: a[k] = L[k][rr], k >= rr
 #define DG_ROW(dg, k) ((k) < rr ? (dg)[(k) * NK - (k) * ((k) - 1) / 2 + rr - (k)] : 0.0)
@@ -1368,9 +1374,10 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     if (wave < 2) __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);  // see twisted_factor
     for (int s = 0; s < nsteps; ++s) {
         double* buf = lds + (s % QP_STAGE_BUFS) * STG;
-        if (wave >= 2) {
+        if (ROLE == 1 || (ROLE < 0 && wave >= 2)) {
             const int sp = s + QP_STAGE_BUFS - 1;
             if (sp < nsteps) stage(sp, lds + (sp % QP_STAGE_BUFS) * STG, tid - 128, QP_THREADS - 128);
+        } else if (ROLE == 1) {
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours, then backward
                 double v = vec[mid * NK + rr];
@@ -1836,13 +1843,14 @@ __device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, 
     return factor_tiled(d, w, flag, lA, lds_avail);
 }
 
+template <int ROLE>
 __device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA, int lds_avail) {
     if (d.nk <= 36) {
         switch (d.nk) {  // lA = start of the dynamic LDS region (the three block buffers are free between factorisations)
-            case 9: solve_staged<9>(d, w, rhs, lA); break;
-            case 18: solve_staged<18>(d, w, rhs, lA); break;
-            case 27: solve_staged<27>(d, w, rhs, lA); break;
-            default: solve_staged<36>(d, w, rhs, lA); break;
+            case 9: solve_staged<9, ROLE>(d, w, rhs, lA); break;
+            case 18: solve_staged<18, ROLE>(d, w, rhs, lA); break;
+            case 27: solve_staged<27, ROLE>(d, w, rhs, lA); break;
+            default: solve_staged<36, ROLE>(d, w, rhs, lA); break;
         }
         return;
     }
@@ -1871,11 +1879,24 @@ __device__ __noinline__ bool factor_entry(BlkArgs b, AsmArgs A, double* lds, int
     blk_unpack(b, d, w);
     return factor_dispatch(d, w, lds, flag, b.lds_avail, b.nk <= 36 ? &A : nullptr);
 }
-__device__ __noinline__ void solve_entry(BlkArgs b, double* rhs, double* lds) {
+__device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* lds) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch(d, w, rhs, lds, b.lds_avail);
+    solve_dispatch<0>(d, w, rhs, lds, b.lds_avail);
+}
+__device__ __noinline__ void solve_entry_stage(BlkArgs b, double* rhs, double* lds) {
+    QpDims d;
+    QpWs w;
+    blk_unpack(b, d, w);
+    solve_dispatch<1>(d, w, rhs, lds, b.lds_avail);
+}
+// (every wave passes the same workgroup barriers in either function)
+__device__ __forceinline__ void solve_entry(const BlkArgs& b, double* rhs, double* lds) {
+    if (b.nk <= 36 && (threadIdx.x >> 6) >= 2)
+        solve_entry_stage(b, rhs, lds);
+    else
+        solve_entry_chain(b, rhs, lds);
 }
 
 #define QP_POLISH_PART 2
