@@ -47,9 +47,12 @@
 #ifndef QP_STAGE_LOADS
 #define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
 #endif
-#ifndef QP_ROW_UNROLL
-#define QP_ROW_UNROLL (QP_WAVES_PER_EU >= 4 ? 1 : 2)  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box, planner time of
-                                                    // the 128-VGPR build: 1: 2094, 2: 2116, 3: 2135, 4: 2172, 8: 2165 ms; single mission (256 VGPRs): 2 is best
+#ifndef QP_ROW_UNROLL  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box, planner time of the 128-VGPR build:
+#if QP_WAVES_PER_EU >= 4  // 1: 2094, 2: 2116, 3: 2135, 4: 2172, 8: 2165 ms; single mission (256 VGPRs): 2 is best
+#define QP_ROW_UNROLL 1
+#else
+#define QP_ROW_UNROLL 2
+#endif
 #endif
 #ifndef QP_SIGMA_POW
 #define QP_SIGMA_POW 3  // Mehrotra's centring exponent
@@ -1199,9 +1202,10 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
 // asmb != nullptr: the knot blocks T_j are ASSEMBLED HERE, by the waves that do not run a chain, in the order the chains consume
 // them (step i: blocks i and nj-1-i; last the middle one), each step announced through an LDS counter (wait_blocks): the
 // assembly -- 8-10 % of an interior-point iteration when it was a phase of its own -- disappears behind the dependent chains.
-template <int NK>
+// ROLE: 0 = compiled for the two chain waves, 1 = for the assembling waves (2..): two __noinline__ functions, see solve_staged.
+template <int NK, int ROLE>
 __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds, const AsmArgs* asmb) {
-    const int wave = threadIdx.x >> 6, mid = twist_mid(d.nj);
+    const int wave = ROLE == 0 ? (threadIdx.x >> 6) & 1 : 2, mid = twist_mid(d.nj);
     const int nl = mid, nr = d.nj - 1 - mid, SF = nl > nr ? nl : nr;
     int* cnt = (int*)(lds + 2 * SYRK_LDS_DOUBLES);  // [SF + 1]
     if (threadIdx.x == 0) *flag = 0;
@@ -1214,11 +1218,13 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     // The chain waves issue one dependent instruction every ~32 cycles; whenever the SIMD's arbiter makes one of them queue
     // behind the ready instructions of other waves (the helpers, the co-resident workgroup's sweeps) the chain stretches, while
     // giving it the first slot costs the others next to nothing: raise the priority for the chain (+2.5 % at 2000 missions).
-    if (wave < 2) __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);
-    if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cw);
-    if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + SYRK_LDS_DOUBLES, cw);
-    if (wave == 1) __builtin_amdgcn_s_setprio(0);
-    if (wave >= 2 && asmb) {
+    if (ROLE == 0) {
+        __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);
+        if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cw);
+        if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + SYRK_LDS_DOUBLES, cw);
+        if (wave == 1) __builtin_amdgcn_s_setprio(0);
+    }
+    if (ROLE == 1 && asmb) {
         const AsmArgs A = *asmb;
         const int per_knot = A.nb * A.nb * 9, ht = threadIdx.x - 128, HT = QP_THREADS - 128;
         const int lane = threadIdx.x & 63;
@@ -1240,7 +1246,7 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     __threadfence_block();
     __syncthreads();
     if (*flag) return false;
-    if (wave == 0) {
+    if (ROLE == 0 && wave == 0) {
         if (!wave_factor_mid<NK>(d, w, lds, cw, SF) && threadIdx.x == 0) *flag = 1;
         __builtin_amdgcn_s_setprio(0);
     }
@@ -1831,15 +1837,17 @@ __device__ void init_block_pads(const QpDims& d, const QpWs& w) {
     }
 }
 
+template <int ROLE>
 __device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, double* lA, int* flag, int lds_avail, const AsmArgs* asmb) {
     if (d.nk <= 36) {
         switch (d.nk) {
-            case 9: return twisted_factor<9>(d, w, flag, lA, asmb);
-            case 18: return twisted_factor<18>(d, w, flag, lA, asmb);
-            case 27: return twisted_factor<27>(d, w, flag, lA, asmb);
-            default: return twisted_factor<36>(d, w, flag, lA, asmb);
+            case 9: return twisted_factor<9, ROLE>(d, w, flag, lA, asmb);
+            case 18: return twisted_factor<18, ROLE>(d, w, flag, lA, asmb);
+            case 27: return twisted_factor<27, ROLE>(d, w, flag, lA, asmb);
+            default: return twisted_factor<36, ROLE>(d, w, flag, lA, asmb);
         }
     }
+    if (ROLE == 1) return true;  // (the assembling role only exists on the wave path)
     return factor_tiled(d, w, flag, lA, lds_avail);
 }
 
@@ -1854,7 +1862,7 @@ __device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, d
         }
         return;
     }
-    solve_tiled(d, w, rhs, lA, lds_avail);
+    if (ROLE != 1) solve_tiled(d, w, rhs, lA, lds_avail);  // (the staging role only exists on the wave path)
 }
 
 
@@ -1873,11 +1881,21 @@ __device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w)
     w.Td = b.Td, w.To = b.To, w.Lf = b.Lf, w.Ek = b.Ek;
 }
 // (inlining these two was measured: 1100 VGPR spills, 31k instead of 51k agent-trajectories/s)
-__device__ __noinline__ bool factor_entry(BlkArgs b, AsmArgs A, double* lds, int* flag) {
+__device__ __noinline__ bool factor_entry_chain(BlkArgs b, AsmArgs A, double* lds, int* flag) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    return factor_dispatch(d, w, lds, flag, b.lds_avail, b.nk <= 36 ? &A : nullptr);
+    return factor_dispatch<0>(d, w, lds, flag, b.lds_avail, b.nk <= 36 ? &A : nullptr);
+}
+__device__ __noinline__ bool factor_entry_assemble(BlkArgs b, AsmArgs A, double* lds, int* flag) {
+    QpDims d;
+    QpWs w;
+    blk_unpack(b, d, w);
+    return factor_dispatch<1>(d, w, lds, flag, b.lds_avail, &A);
+}
+__device__ __forceinline__ bool factor_entry(const BlkArgs& b, const AsmArgs& A, double* lds, int* flag) {
+    if (b.nk <= 36 && (threadIdx.x >> 6) >= 2) return factor_entry_assemble(b, A, lds, flag);
+    return factor_entry_chain(b, A, lds, flag);
 }
 __device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* lds) {
     QpDims d;
