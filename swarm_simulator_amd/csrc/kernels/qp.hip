@@ -44,6 +44,22 @@
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
+#ifndef QP_SOLVE_UNROLL_N  // dependent column loops of the substitutions (0 = completely unrolled).  A/B on one box: the 128-VGPR build gains
+#if QP_WAVES_PER_EU >= 4   // 3.6 % of the planner time with 6, 12 or 18 (the fully unrolled loops let the scheduler hoist LDS loads until it spills
+#define QP_SOLVE_UNROLL_N 12  // on the chain); the 256-VGPR build preloads the factor row into registers and needs the full unroll (208 vs 263 ms)
+#else
+#define QP_SOLVE_UNROLL_N 0
+#endif
+#endif
+#if QP_SOLVE_UNROLL_N == 0
+#define QP_SOLVE_UNROLL _Pragma("unroll")
+#elif QP_SOLVE_UNROLL_N == 6
+#define QP_SOLVE_UNROLL _Pragma("unroll 6")
+#elif QP_SOLVE_UNROLL_N == 12
+#define QP_SOLVE_UNROLL _Pragma("unroll 12")
+#else
+#define QP_SOLVE_UNROLL _Pragma("unroll 18")
+#endif
 #ifndef QP_STAGE_LOADS
 #define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
 #endif
@@ -1393,14 +1409,14 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 const double inv = dgm[rr * NK - rr * (rr - 1) / 2];  // 1 / d_rr
                 LROW_DECL;
                 LROW_LOAD(DG_ROW(dgm, c));
-#pragma unroll
+QP_SOLVE_UNROLL
                 for (int c = 0; c < NK; ++c) {
                     const double xc = rl(v, c);
                     v -= LROW(c, DG_ROW(dgm, c)) * xc;  // 0 for lanes r <= c: no select on the dependent chain
                 }
                 v *= inv;
                 LROW_LOAD(DG_COL(dgm, c));
-#pragma unroll
+QP_SOLVE_UNROLL
                 for (int c = NK - 1; c >= 0; --c) {
                     const double xc = rl(v, c);
                     v -= LROW(c, DG_COL(dgm, c)) * xc;
@@ -1423,7 +1439,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 if (fwd) {
                     LROW_LOAD(DG_ROW(dgp, c));
                     if (has_nb) v -= dot_lanes(bl + rr, LDP, prev);
-#pragma unroll
+QP_SOLVE_UNROLL
                     for (int c = 0; c < NK; ++c) {
                         const double xc = rl(v, c);
                         v -= LROW(c, DG_ROW(dgp, c)) * xc;
@@ -1433,7 +1449,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                     LROW_LOAD(DG_COL(dgp, c));
                     const double t = first_bwd ? dot_rows(bl + rr * LDP, 1, vec + mid * NK) : dot_lanes(bl + rr * LDP, 1, prev);
                     v -= inv * t;
-#pragma unroll
+QP_SOLVE_UNROLL
                     for (int c = NK - 1; c >= 0; --c) {
                         const double xc = rl(v, c);
                         v -= LROW(c, DG_COL(dgp, c)) * xc;
