@@ -60,6 +60,16 @@
 #else
 #define QP_SOLVE_UNROLL _Pragma("unroll 18")
 #endif
+#ifndef QP_DOT_UNROLL_N  // coupling-block dot products of the substitutions: groups of four terms unrolled (0 = all nine).  A/B on one box:
+#define QP_DOT_UNROLL_N 3  // 3 gives the single mission -2 % (208 -> 204 ms), throughput unchanged
+#endif
+#if QP_DOT_UNROLL_N == 0
+#define QP_DOT_UNROLL _Pragma("unroll")
+#elif QP_DOT_UNROLL_N == 1
+#define QP_DOT_UNROLL _Pragma("unroll 1")
+#else
+#define QP_DOT_UNROLL _Pragma("unroll 3")
+#endif
 #ifndef QP_STAGE_LOADS
 #define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
 #endif
@@ -1357,7 +1367,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     // cycles each)
     auto dot_rows = [&](const double* blk_col0, int stride_k, const double* xs) {  // sum_k blk[k*stride] * xs[k], xs in LDS
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
+QP_DOT_UNROLL
         for (int k = 0; k < NK; k += 4) {
             s0 += blk_col0[k * stride_k] * xs[k];
             if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * xs[k + 1];
@@ -1368,7 +1378,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     };
     auto dot_lanes = [&](const double* blk_col0, int stride_k, double xv) {  // same with xs[k] = lane k's xv
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-#pragma unroll
+QP_DOT_UNROLL
         for (int k = 0; k < NK; k += 4) {
             s0 += blk_col0[k * stride_k] * rl(xv, k);
             if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * rl(xv, k + 1);
