@@ -179,3 +179,34 @@ def test_batch_iter_zero_publishes_initial_trajectory():
     assert np.abs(g.coef - ref.coef).max() < 1e-12 * max(1.0, np.abs(ref.coef).max())
     # coefficient of (t - T_m)^0 is the first control point of the segment = waypoint m
     assert np.allclose(g.coef[:, :, 5::6], np.transpose(g.init_traj[:, :-1, :].astype(np.float64), (0, 2, 1)), atol=1e-12)
+
+
+def test_resident_copies_of_a_mission_agree_bit_for_bit():
+    """600 missions resident (12 copies of each map of the sweep): more workgroups than CUs, so the two-per-CU build runs with
+    co-resident workgroups, the dispatcher hands missions out in a different order every time, and every hand-over inside a workgroup
+    (knot blocks assembled by the helper waves behind the factorisation chains, staged factor blocks, the dual solve) happens under
+    different timing.  Every copy of a map must still give the same bits -- control points, interior-point iteration count, cost --
+    and so must a second run of the whole session."""
+    import bench
+    K = 600
+    p = Param.test_sweep()
+    m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), 64, p)
+    s = planner.Session(worlds, [m] * K, p, plans)
+    first = None
+    for rep in range(2):
+        s.reset()
+        s.run()
+        st = s.download()
+        assert not np.any(st)
+        it = s.scalars(28)[:, 2].copy()
+        ctrl = [pl.ctrl.copy() for pl in s.plans]
+        cost = np.array([pl.total_cost for pl in s.plans])
+        for k in range(50, K):
+            assert it[k] == it[k % 50] and cost[k] == cost[k % 50], f"mission {k} (copy of map {k % 50 + 1})"
+            assert np.array_equal(ctrl[k].view(np.uint64), ctrl[k % 50].view(np.uint64)), f"mission {k}"
+        if first is None:
+            first = (it, ctrl)
+        else:
+            assert np.array_equal(it, first[0])
+            assert all(np.array_equal(a.view(np.uint64), b.view(np.uint64)) for a, b in zip(ctrl, first[1]))
+    s.close()
