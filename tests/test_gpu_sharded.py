@@ -35,7 +35,8 @@ def test_range_shards_tile_the_full_corridor(n_shards):
 
 def test_c4_256_agents_single_rank():
     """config C4 (256 agents, tools/make_mission_256.py) through plan_sharded with one rank: corridor bit-exact against the
-    CPU checker, the QP sweep (64 batches, 252 frozen neighbours each) feasible and all equalities met."""
+    CPU checker, the QP sweep (64 batches, 252 frozen neighbours each) feasible, all equalities met, every batch QP polished,
+    and three of the batch QPs certified optimal by the independent numpy restatement."""
     p = Param.test_sweep(**C4_PARAM)
     m = host.load_mission("mission_256agents_c4.json")
     assert m.qn == 256
@@ -50,3 +51,15 @@ def test_c4_256_agents_single_rank():
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
     assert veq < 1e-8 and vbox < 1e-8 and vrs < 1e-8
     assert abs(obj - gpu.total_cost) < 1e-6 * max(1.0, obj)
+    assert gpu.qp_unpolished == 0 and gpu.qp_solves == 64
+    # optimality, not only feasibility: the independent numpy certificate (tests/golden/make_kkt_reference.py) on the first, a middle
+    # and the last batch QP of the sweep (4 agents against 252 frozen neighbours each)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_kkt_reference as K
+    for rep in K.certify_plan(init.T, init.init_traj, m.start, m.goal, m.radius, gpu.sfc_box, ref.sfc_time, gpu.sfc_count, gpu.rsfc_normal,
+                              ref.rsfc_time, gpu.ctrl, p.sequential, p.batch_size, p.batch_iter, only_batches=[0, 31, 63]):
+        tag = f"C4 batch {rep['batch']}: " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
+        assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
+        assert rep["forward_error"] < 2e-6, tag
