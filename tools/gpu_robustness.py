@@ -19,13 +19,7 @@ for mf in sys.argv[1:]:
     if not plans:
         print(f"{mf}: ECBS found no initial trajectory on any map, skipped")
         continue
-    M = max(q.M for q in plans)
-    pl2 = []
-    for q in plans:
-        pad = M - q.M
-        traj = np.concatenate([q.init_traj, np.repeat(q.init_traj[:, -1:, :], pad, axis=1)], axis=1)
-        T = np.concatenate([q.T, q.T[-1] + np.arange(1, pad + 1)])
-        pl2.append(PlanResult(traj, T))
+    pl2 = plans  # ragged session: every map keeps its own M = makespan + 2
     s = planner.Session(worlds, [m] * len(pl2), p, pl2)
     t = time.time(); s.run(); st = s.download(); dt = time.time() - t
     sc = s.scalars()
