@@ -325,12 +325,13 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s (reference-equivalent sample bytes, not physical)",
                              "frac": sfc_bytes / (corridor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "samples_per_step": ct["sfc_samples"]},
         }
-        if N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint and not args.no_latency:
+        # the single-mission latency and the CPU baseline are rank-0, N = 1 legs (the other ranks would only wait for them)
+        if world_size == 1 and N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint and not args.no_latency:
             try:
                 out["latency_ms_single_mission"] = single_mission_latency(mission, param, worlds[0], plans[0])
             except Exception as e:
                 out["latency_ms_single_mission"] = {"error": str(e)}
-        if not args.no_cpu_baseline:
+        if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.agents, pkw)
             except Exception as e:  # the oracle is optional equipment of the bench
