@@ -1900,24 +1900,40 @@ struct BlkArgs {
     double *Td, *To, *Lf;
     double* Ek;
 };
+// Arguments of a non-kernel function arrive in VECTOR registers, and the compiler treats them as divergent: every pointer, dimension and
+// address derived from them would live in VGPRs for the whole function -- in the 128-VGPR build that is what spills inside the knot
+// loops, and a spill reload on a dependent chain costs a memory round trip.  They are wave-uniform by construction, so they are moved to
+// scalar registers explicitly (v_readfirstlane); everything computed from them then stays scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w) {
     d = QpDims{};
     w = QpWs{};
-    d.nk = b.nk, d.nj = b.nj, d.ldb = b.ldb, d.ld = b.nk + 1;
-    w.Td = b.Td, w.To = b.To, w.Lf = b.Lf, w.Ek = b.Ek;
+    d.nk = uni(b.nk), d.nj = uni(b.nj), d.ldb = uni(b.ldb), d.ld = d.nk + 1;
+    w.Td = uni(b.Td), w.To = uni(b.To), w.Lf = uni(b.Lf), w.Ek = uni(b.Ek);
+}
+__device__ __forceinline__ AsmArgs uni(const AsmArgs& A) {
+    return AsmArgs{uni(A.cpacc), uni(A.pwgt), uni(A.Lk), uni(A.Dk), uni(A.normals), uni(A.Td), uni(A.N), uni(A.M), uni(A.nb), uni(A.first), uni(A.oq), uni(A.ldb)};
 }
 // (inlining these two was measured: 1100 VGPR spills, 31k instead of 51k agent-trajectories/s)
 __device__ __noinline__ bool factor_entry_chain(BlkArgs b, AsmArgs A, double* lds, int* flag) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    return factor_dispatch<0>(d, w, lds, flag, b.lds_avail, b.nk <= 36 ? &A : nullptr);
+    const AsmArgs Au = uni(A);
+    return factor_dispatch<0>(d, w, uni(lds), uni(flag), uni(b.lds_avail), d.nk <= 36 ? &Au : nullptr);
 }
 __device__ __noinline__ bool factor_entry_assemble(BlkArgs b, AsmArgs A, double* lds, int* flag) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    return factor_dispatch<1>(d, w, lds, flag, b.lds_avail, &A);
+    const AsmArgs Au = uni(A);
+    return factor_dispatch<1>(d, w, uni(lds), uni(flag), uni(b.lds_avail), &Au);
 }
 __device__ __forceinline__ bool factor_entry(const BlkArgs& b, const AsmArgs& A, double* lds, int* flag) {
     if (b.nk <= 36 && (threadIdx.x >> 6) >= 2) return factor_entry_assemble(b, A, lds, flag);
@@ -1927,13 +1943,13 @@ __device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* l
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<0>(d, w, rhs, lds, b.lds_avail);
+    solve_dispatch<0>(d, w, uni(rhs), uni(lds), uni(b.lds_avail));
 }
 __device__ __noinline__ void solve_entry_stage(BlkArgs b, double* rhs, double* lds) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<1>(d, w, rhs, lds, b.lds_avail);
+    solve_dispatch<1>(d, w, uni(rhs), uni(lds), uni(b.lds_avail));
 }
 // (every wave passes the same workgroup barriers in either function)
 __device__ __forceinline__ void solve_entry(const BlkArgs& b, double* rhs, double* lds) {
