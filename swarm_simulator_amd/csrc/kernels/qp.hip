@@ -70,6 +70,9 @@
 #else
 #define QP_DOT_UNROLL _Pragma("unroll 3")
 #endif
+#ifndef QP_UNI_POLISH
+#define QP_UNI_POLISH 1
+#endif
 #ifndef QP_STAGE_LOADS
 #define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
 #endif
