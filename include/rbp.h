@@ -15,6 +15,7 @@
 #ifndef RBP_H
 #define RBP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -180,7 +181,7 @@ typedef struct rbp_counters {
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 
-/* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 24 (layout: kernels/rbp_dev.h SC_*) */
+/* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 28 = SC_N (layout: kernels/rbp_dev.h SC_*) */
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
 
 /* ---- contexts: device memory kept across calls -------------------------------------------------
@@ -201,7 +202,17 @@ int rbp_ctx_plan_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission*
 int rbp_session_create_in(rbp_ctx* ctx, rbp_session** out, int K, const rbp_world* worlds, const rbp_mission* missions,
                           const rbp_param* param, const rbp_plan* plans);
 
-/* library/version/diagnostics */
+/* the calling thread's default context (see above) is released when the thread exits; a long-lived thread that is done planning
+ * can give the arena back earlier */
+void rbp_release_thread_context(void);
+
+/* library/version/diagnostics.  RBP_ABI_VERSION changes whenever a struct of this header changes its layout; a binding built
+ * against another header must refuse to run (rbp_plan / rbp_counters are written by the library).  rbp_sizeof lets a binding
+ * that cannot see this header (ctypes, cgo) compare its own struct sizes with the library's. */
+#define RBP_ABI_VERSION 3  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: this header */
+enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4 };
+int rbp_abi_version(void);
+size_t rbp_sizeof(int which);
 const char* rbp_version(void);
 /* ---- distance grid of a world on the GPU ---------------------------------
  * What  DynamicEDTOctomap distmap(max_dist, tree, bbx_min, bbx_max, false); distmap.update();  followed by getDistance() on every

@@ -28,6 +28,8 @@ RBP_ERR_BAD_ARGUMENT = 20
 RBP_ERR_NO_DEVICE = 30
 RBP_ERR_HIP = 31
 
+RBP_ABI_VERSION = 3  # include/rbp.h
+
 RBP_STAGE_CORRIDOR = 1
 RBP_STAGE_PLANNER = 2
 RBP_STAGE_ALL = 3

@@ -78,11 +78,24 @@ struct rbp_session {
     std::vector<double> sfc_box0, sfc_time0, rsfc_time0;
     std::vector<float> rsfc_normal0;
     bool have_corridor_inputs = false;
+    bool planner_ok = true;   // false: the batch is wider than the QP kernel supports (corridor-only session)
+    int last_stages = 0;      // stages of the last rbp_session_run (time_scale only concerns a run that included the planner)
 };
 
 extern "C" {
 
-const char* rbp_version(void) { return "rbp-mi355x 0.1 (gfx950)"; }
+const char* rbp_version(void) { return "rbp-mi355x 0.3 (gfx950)"; }
+int rbp_abi_version(void) { return RBP_ABI_VERSION; }
+size_t rbp_sizeof(int which) {
+    switch (which) {
+        case RBP_SIZEOF_WORLD: return sizeof(rbp_world);
+        case RBP_SIZEOF_MISSION: return sizeof(rbp_mission);
+        case RBP_SIZEOF_PARAM: return sizeof(rbp_param);
+        case RBP_SIZEOF_PLAN: return sizeof(rbp_plan);
+        case RBP_SIZEOF_COUNTERS: return sizeof(rbp_counters);
+        default: return 0;
+    }
+}
 const char* rbp_last_error(void) { return g_err.c_str(); }
 
 int rbp_device_count(void) {
@@ -148,7 +161,10 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     }
     int bs = 1, biter = 0;
     batch_schedule(*param, N, &bs, &biter);
-    if (biter > 0 && bs > planner_max_batch()) return fail(RBP_ERR_BAD_ARGUMENT, "batch wider than " + std::to_string(planner_max_batch()) + " agents (joint QP of a large mission) is not supported by the QP kernel");
+    // a batch wider than the QP kernel factorises (the joint QP of a mission with more than planner_max_batch() agents) only
+    // concerns the PLANNER stage: such a session can still run the corridor (rbp_corridor_update*, the sharded corridor); the
+    // planner stage is refused in rbp_session_run and no QP workspace is reserved
+    const bool planner_ok = !(biter > 0 && bs > planner_max_batch());
 
     struct Guard {  // every error path below releases the session (and with it the arena)
         rbp_session* s;
@@ -162,7 +178,8 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     s->Mk.resize(K), s->MBk.resize(K);
     for (int k = 0; k < K; ++k) s->Mk[k] = plans[k].M, s->MBk[k] = plans[k].max_boxes;
     const int P = M + 1, npair = N * (N - 1) / 2, oq = 6 * M;
-    s->qp_ws_per_mission = std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs));
+    s->planner_ok = planner_ok;
+    s->qp_ws_per_mission = planner_ok ? std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs)) : 0;
     {
         hipDeviceProp_t prop;
         s->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -365,6 +382,10 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
+    if ((stages & RBP_STAGE_PLANNER) && !s->planner_ok)
+        return fail(RBP_ERR_BAD_ARGUMENT, "batch wider than " + std::to_string(planner_max_batch()) +
+                                              " agents (joint QP of a large mission) is not supported by the QP kernel");
+    s->last_stages = stages;
     if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
     if (stages & RBP_STAGE_PLANNER) {
         // two workgroups per CU (the 128-VGPR build) pay off as soon as there are more missions than CUs: the 256-VGPR build
@@ -403,7 +424,9 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
         const double* q = &sc[(size_t)k * SC_N];
         // timeScale (rbp_planner.hpp:250-264) multiplies T, the SFC end times and the RSFC times by time_scale: done here, on
         // the host copies (the same IEEE products), because the device arrays stay unscaled (see rbp_session_reset)
-        const double ts = q[SC_TIME_SCALE] > 0 ? q[SC_TIME_SCALE] : 1.0;
+        // ... and only when the last run included the planner: after a CORRIDOR-only run the scalar still holds the factor of
+        // an earlier planner run, which has nothing to do with the corridor times just written
+        const double ts = ((s->last_stages & RBP_STAGE_PLANNER) && q[SC_TIME_SCALE] > 0) ? q[SC_TIME_SCALE] : 1.0;
         DN(p.T, d.T + (size_t)k * P, sizeof(double) * Pq);
         if (ts != 1.0)
             for (int m = 0; m < Pq; ++m) p.T[m] *= ts;
@@ -524,6 +547,32 @@ void rbp_ctx_destroy(rbp_ctx* c) {
     delete c;
 }
 
+// The per-thread default context of the drop-in calls.  A worker thread that exits gives its arena back (hipFree); at process
+// exit the HIP runtime may already be gone when thread_local destructors run, so from the first atexit handler on nothing is
+// freed any more (the runtime releases device memory itself).  rbp_release_thread_context() frees it on request.
+namespace {
+bool g_process_exiting = false;
+struct Tls {
+    rbp_ctx* c = nullptr;
+    ~Tls() {
+        if (c && !g_process_exiting) rbp_ctx_destroy(c);
+        c = nullptr;
+    }
+};
+Tls& tls_ctx() {
+    static const int registered = (atexit([] { g_process_exiting = true; }), 0);
+    (void)registered;
+    thread_local Tls tls;
+    return tls;
+}
+}  // namespace
+
+void rbp_release_thread_context(void) {
+    Tls& tls = tls_ctx();
+    if (tls.c) rbp_ctx_destroy(tls.c);
+    tls.c = nullptr;
+}
+
 static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan,
                     int stages, int agent_begin = 0, int agent_end = -1) {
     if (!mission || !param || !plan) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
@@ -544,10 +593,7 @@ static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mis
     }
     // without an explicit context the calling thread's own one is used (created on first use on its current device), so the
     // drop-in calls do not allocate device memory per plan either
-    thread_local struct Tls {
-        rbp_ctx* c = nullptr;
-        ~Tls() { /* process exit: the runtime releases device memory; hipFree here could run after the runtime is gone */ }
-    } tls;
+    Tls& tls = tls_ctx();
     if (!ctx) {
         int dev = 0;
         (void)hipGetDevice(&dev);

@@ -2652,11 +2652,9 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
     hipLaunchKernelGGL(dummy_kernel, dim3(g), dim3(256), 0, st, s);
     if (biter > 0) {
         if (bs > QP_MAX_NB) {
-            // nk > 72 needs the tiled multi-workgroup factorisation (joint mode with N > 8): not in this round.
-            // Fail loudly: every mission gets RBP_ERR_BAD_ARGUMENT.
-            std::vector<int> bad(s.K, (int)RBP_ERR_BAD_ARGUMENT);
-            (void)hipMemcpyAsync(s.status, bad.data(), sizeof(int) * s.K, hipMemcpyHostToDevice, st);
-            (void)hipStreamSynchronize(st);
+            // a batch wider than QP_MAX_NB agents (nk > 576: the joint QP of a mission with more than 64 agents) is refused by
+            // rbp_session_run before any launch (abi/session.hip); reaching this line is an internal error
+            (void)rbp_set_error(RBP_ERR_BAD_ARGUMENT, "launch_planner: batch wider than the QP kernel supports");
             return;
         }
         const int nk = 9 * bs;

@@ -42,6 +42,19 @@ def lib():
         L = C.CDLL(path)
         P = C.POINTER
         L.rbp_version.restype = C.c_char_p
+        # the structs of include/rbp.h are written by the library: refuse a library built from another header
+        if os.environ.get("RBP_HIP_LIB") and not hasattr(L, "rbp_abi_version"):
+            pass  # (developer A/B builds of older commits predate the check)
+        else:
+            L.rbp_abi_version.restype = C.c_int
+            L.rbp_sizeof.restype = C.c_size_t
+            L.rbp_sizeof.argtypes = [C.c_int]
+            if L.rbp_abi_version() != A.RBP_ABI_VERSION:
+                raise RbpLibraryMissing(f"{path}: ABI version {L.rbp_abi_version()}, this binding expects {A.RBP_ABI_VERSION} (rebuild the library)")
+            for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters)):
+                if L.rbp_sizeof(which) != C.sizeof(t):
+                    raise RbpLibraryMissing(f"{path}: sizeof({t.__name__}) is {L.rbp_sizeof(which)} in the library, {C.sizeof(t)} in this binding")
+            L.rbp_release_thread_context.restype = None
         L.rbp_last_error.restype = C.c_char_p
         L.rbp_device_count.restype = C.c_int
         L.rbp_param_defaults.argtypes = [P(A.rbp_param)]
@@ -81,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
     "rbp_session_run", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
-    "rbp_version",
+    "rbp_version", "rbp_abi_version", "rbp_sizeof", "rbp_release_thread_context",
     "rbp_last_error", "rbp_device_count",
     "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
     "rbp_session_create_in",

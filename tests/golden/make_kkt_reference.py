@@ -309,14 +309,19 @@ def certify_batch(qp: BatchQP, x, tau=2e-8):
 
 
 def certify_plan(T0, init_traj, start, goal, radius, sfc_box, sfc_time, sfc_count, rsfc_normal, rsfc_time, ctrl, sequential,
-                 batch_size, batch_iter, tau=2e-8, only_batches=None):
-    """plan/iteration = 1: every batch QP of solveQP's single pass, reconstructed from the FINAL control points `ctrl`
-    ([N][3][6M]): frozen agents of batches < l at their final values, of batches > l at build_dummy.  Returns one report per batch."""
+                 batch_size, batch_iter, tau=2e-8, only_batches=None, ctrl_before_pass=None):
+    """every batch QP of solveQP's LAST pass, reconstructed from the FINAL control points `ctrl` ([N][3][6M]): frozen agents of
+    batches < l at their final values, of batches > l at the values they had when the pass began -- build_dummy for plan/iteration
+    = 1 (:116), the control points after the previous pass for plan/iteration > 1 (`ctrl_before_pass`, [N][3][6M]: `dummy` is only
+    ever overwritten by :183-185).  Returns one report per batch."""
     T0 = np.asarray(T0, np.float64)
     N = start.shape[0]
     lo, hi = select_boxes(T0, sfc_box, sfc_time, sfc_count)
     normals = select_normals(T0, rsfc_normal, rsfc_time)
     dummy = build_dummy(init_traj)
+    if ctrl_before_pass is not None:
+        for qi in range(N):
+            dummy[qi] = np.asarray(ctrl_before_pass)[qi].T
     bl, biter = batches(N, sequential, batch_size, batch_iter)
     reports = []
     for l in range(biter):

@@ -90,3 +90,15 @@ def test_planner_call_without_corridor_is_refused():
     pl = planner.RBPPlanner(c.mission, c.param)
     assert pl.update(False, pr) is False
     assert pl.rc == A.RBP_ERR_BAD_ARGUMENT and "corridor" in pl.last_error
+
+
+def test_abi_version_and_struct_sizes_match_the_binding():
+    """rbp_plan / rbp_counters are written by the library: a binding built against another header must not run"""
+    L = planner.lib()
+    hdr = open(os.path.join(A.REPO_ROOT, "include", "rbp.h")).read()
+    assert int(re.search(r"#define RBP_ABI_VERSION (\d+)", hdr).group(1)) == A.RBP_ABI_VERSION == L.rbp_abi_version()
+    for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters)):
+        assert L.rbp_sizeof(which) == C.sizeof(t), t.__name__
+    assert L.rbp_sizeof(99) == 0
+    assert b"0.3" in L.rbp_version()
+    L.rbp_release_thread_context()   # nothing to release: must be harmless without a device

@@ -1,0 +1,137 @@
+"""Round-3 parity additions (VERDICT r02 "next round" item 5 and the ADVICE items).  Needs an MI355X.
+
+* C5 (batch 8 x 50 passes) on the 64-agent mission: every batch QP polished (or KKT residual < 1e-7) and three batch QPs of the
+  LAST pass certified optimal by the independent numpy restatement (tests/golden/make_kkt_reference.py), which for plan/iteration
+  > 1 needs the control points the pass started from (a second, 49-pass run: the kernel is bit-reproducible);
+* a mission with MIXED radii (the reference's quad_size is per agent, mission.hpp:64): corridor bit-exact (the SFC kernel reads
+  the float grid for agents whose radius differs from agent 0's, whose bit mask the workgroup shares), QP against the oracle;
+* corridor-only use of a session whose joint batch the QP kernel cannot take; stale time_scale after a corridor-only run.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param, PlanResult
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CTRL_TOL = 2e-6
+FEAS_TOL = 1e-8
+EQ_TOL = 5e-8
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _kkt():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_kkt_reference as K
+    return K
+
+
+def test_c5_64_agents_last_pass_certified():
+    m = host.load_mission("mission_64agents_15.json")
+    out = {}
+    for it in (49, 50):
+        p = Param.test_sweep(batch_size=8, iteration=it)
+        w = host.load_world("map1.bt", p)
+        g = host.ecbs_plan(w, m, p)
+        T0 = g.T.copy()
+        assert planner.Corridor(w, m, p).update(False, g)
+        corr = g.clone()          # corridor times before timeScale
+        pl = planner.RBPPlanner(m, p)
+        assert pl.update(False, g), pl.last_error
+        assert g.qp_solves == 8 * it
+        assert g.qp_unpolished == 0 or g.kkt_max < 1e-7, (g.qp_unpolished, g.kkt_max)
+        out[it] = (g, corr, T0)
+    g, corr, T0 = out[50]
+    K = _kkt()
+    reps = K.certify_plan(T0, g.init_traj, m.start, m.goal, m.radius, g.sfc_box, corr.sfc_time, g.sfc_count, g.rsfc_normal,
+                          corr.rsfc_time, g.ctrl, True, 8, -1, only_batches=[0, 3, 7], ctrl_before_pass=out[49][0].ctrl)
+    assert len(reps) == 3
+    for rep in reps:
+        tag = f"batch {rep['batch']}: " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
+        assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
+        assert rep["forward_error"] < CTRL_TOL, tag
+
+
+def _mixed_mission():
+    m = host.load_mission("mission_16agents_15.json")
+    m.radius = m.radius.copy()
+    m.radius[[3, 7]] = 0.2          # mission.hpp:64: quad_size is per agent
+    return m
+
+
+def test_mixed_radius_corridor_bit_exact_and_qp_vs_oracle():
+    p = Param.test_sweep()
+    m = _mixed_mission()
+    w = host.load_world("map3.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    rc, ns = O.corridor_update(w, m, p, ref)
+    assert rc == 0
+    sess = planner.Session([w], [m], p, [gpu])
+    sess.run(A.RBP_STAGE_CORRIDOR)
+    assert sess.download() == [0]
+    assert np.array_equal(ref.sfc_count, gpu.sfc_count) and np.array_equal(ref.sfc_box, gpu.sfc_box)
+    assert np.array_equal(ref.sfc_time, gpu.sfc_time)
+    assert np.array_equal(bits(ref.rsfc_normal), bits(gpu.rsfc_normal))
+    assert int(sess.counters()["sfc_samples"]) == ns
+    sess.close()
+    # the wider agents really get other boxes than they would with the common radius (the test would be vacuous otherwise)
+    m0 = host.load_mission("mission_16agents_15.json")
+    same = init.clone_inputs()
+    assert O.corridor_update(w, m0, p, same)[0] == 0
+    assert not np.array_equal(same.sfc_box[[3, 7]], ref.sfc_box[[3, 7]])
+    rc, rep = O.planner_update(m, p, ref)
+    assert rc == 0
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu), pl.last_error
+    assert gpu.qp_unpolished == 0
+    assert np.abs(ref.ctrl - gpu.ctrl).max() < CTRL_TOL
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
+def test_corridor_only_session_with_a_joint_batch_wider_than_the_qp_kernel():
+    """plan/sequential=false is the reference's code default (param.hpp:67): setBatch makes one batch of all N agents.  For N above
+    the QP kernel's widest batch the PLANNER stage is refused -- but Corridor::update has nothing to do with the batch width."""
+    p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
+    m = host.load_mission("mission_256agents_c4.json")
+    w = host.load_world("map1.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    cor = planner.Corridor(w, m, p)
+    assert cor.update(False, gpu), cor.last_error
+    assert np.array_equal(ref.sfc_box, gpu.sfc_box) and np.array_equal(bits(ref.rsfc_normal), bits(gpu.rsfc_normal))
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu) is False and pl.rc == A.RBP_ERR_BAD_ARGUMENT and "batch wider" in pl.last_error
+
+
+def test_corridor_only_run_after_a_planner_run_is_not_time_scaled():
+    """rbp_session_download multiplies T / SFC / RSFC times by time_scale on the host; after a CORRIDOR-only run that factor
+    (left by an earlier planner run of the same session) does not apply"""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_8agents_15.json")
+    m.max_vel = m.max_vel * 0.25      # force time_scale > 1
+    w = host.load_world("map5.bt", p)
+    g = host.ecbs_plan(w, m, p)
+    T0 = g.T.copy()
+    sess = planner.Session([w], [m], p, [g])
+    sess.run(A.RBP_STAGE_ALL)
+    assert sess.download() == [0]
+    assert g.time_scale > 1.0 and np.allclose(g.T, T0 * g.time_scale, rtol=0, atol=1e-12)
+    scaled = g.sfc_time.copy()
+    sess.run(A.RBP_STAGE_CORRIDOR)
+    assert sess.download() == [0]
+    assert g.time_scale == 1.0 and np.array_equal(g.T, T0)
+    assert np.allclose(g.sfc_time * 1.0, scaled / scaled.max() * g.sfc_time.max(), rtol=1e-12, atol=0)  # same boxes, unscaled
+    assert g.sfc_time.max() == T0[-1]
+    sess.close()
