@@ -64,14 +64,14 @@ def test_c5_64_agents_last_pass_certified():
 def _mixed_mission():
     m = host.load_mission("mission_16agents_15.json")
     m.radius = m.radius.copy()
-    m.radius[[3, 7]] = 0.2          # mission.hpp:64: quad_size is per agent
+    m.radius[[3, 4, 7]] = 0.25      # mission.hpp:64: quad_size is per agent (on map1.bt this radius changes the boxes of all three)
     return m
 
 
 def test_mixed_radius_corridor_bit_exact_and_qp_vs_oracle():
     p = Param.test_sweep()
     m = _mixed_mission()
-    w = host.load_world("map3.bt", p)
+    w = host.load_world("map1.bt", p)
     init = host.ecbs_plan(w, m, p)
     ref, gpu = init.clone_inputs(), init.clone_inputs()
     rc, ns = O.corridor_update(w, m, p, ref)
@@ -88,7 +88,7 @@ def test_mixed_radius_corridor_bit_exact_and_qp_vs_oracle():
     m0 = host.load_mission("mission_16agents_15.json")
     same = init.clone_inputs()
     assert O.corridor_update(w, m0, p, same)[0] == 0
-    assert not np.array_equal(same.sfc_box[[3, 7]], ref.sfc_box[[3, 7]])
+    assert all(not np.array_equal(same.sfc_box[a], ref.sfc_box[a]) for a in (3, 4, 7))
     rc, rep = O.planner_update(m, p, ref)
     assert rc == 0
     pl = planner.RBPPlanner(m, p)
