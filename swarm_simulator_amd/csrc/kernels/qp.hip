@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "rbp_dev.h"
+#include "knot_lds.inc"
 
 // The QP is tolerance-judged floating point: allow FMA contraction here (the Makefile disables it globally because
 // corridor.hip must round exactly like the reference's float32 code).
@@ -102,7 +103,7 @@
 #define QP_CHAIN_PRIO 3  // s_setprio level of the waves that run a dependent chain (factor, substitutions, dual active-set solve)
 #endif
 #ifndef QP_STAGE_BUFS
-#define QP_STAGE_BUFS (QP_WAVES_PER_EU >= 4 ? 2 : 3)
+#define QP_STAGE_BUFS (QP_THREADS >= 512 ? 3 : 2)  // (the 256-thread build shares a CU's LDS between two workgroups)
 #endif
 #ifndef QP_RCP_NEWTON
 #define QP_RCP_NEWTON 2
@@ -833,10 +834,8 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds) {
 // substitutions run in ONE wavefront with matrix rows held in VGPRs (lane r = row r, NK doubles per block) and
 // v_readlane broadcasts instead of LDS traffic: every step of the dependent chains costs a few issue cycles
 // instead of an LDS round trip, and no workgroup barrier is needed inside a knot.
-//   Lf[j][0] = L_jj      stored [k][r] (lane r writes its row coalesced)
-//   Lf[j][1] = L_{j+1,j} stored [k][r]
-// The substitutions stage these blocks through LDS (prefetched by the otherwise idle waves) and read rows or
-// columns from there.
+// (Round 3: the cross-lane traffic of the factorisation goes through LDS broadcasts instead, see knot_lds.inc; v_readlane is
+// left for the pivots.)  The substitutions stage the knots' M_j through LDS (prefetched by the otherwise idle waves).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double rl(double v, int lane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -847,9 +846,7 @@ __device__ __forceinline__ double rl(double v, int lane) {
 // TWISTED ("burn at both ends") factorisation: wave 0 eliminates blocks 0 .. mid-1 upwards, wave 1 eliminates blocks
 // nj-1 .. mid+1 downwards, concurrently on two SIMDs; the middle block collects both Schur complements.  It halves the
 // length of the dependent chain (factor and substitutions alike) at no extra arithmetic.
-//   Lf[j][0] = L_jj                                    stored [k][r] (element (r,k) at k*NK + r)
-//   Lf[j][1] = coupling factor produced with block j:  j < mid: B_{j+1} = T_{j+1,j} L_jj^{-T}  (rows of block j+1)
-//                                                      j > mid: C_{j-1} = T_{j-1,j} L_jj^{-T}  (rows of block j-1)
+//   Lf[j] = M_j = L_j^-T (row r contiguous, zeros left of the diagonal), then 1 / d_j   (KF_STRIDE doubles per knot)
 __device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
 
 // Progress counters of the just-in-time block assembly (LDS ints behind the two chain areas): cnt[i] counts the helper waves that
@@ -860,119 +857,11 @@ __device__ __forceinline__ void wait_blocks(int* cnt, int i) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// row r of the coupling block towards the next block of a chain.  T_{j+1,j}[r][k] = E_{knot j+1}[k%3][r%3] on the
-// (agent,dim) diagonal (assemble_blocks), T_{j-1,j} = T_{j,j-1}'.
-template <int NK>
-__device__ __forceinline__ void coupling_row(const QpWs& w, int j, int dir, int rr, double (&b)[NK]) {
-    if (dir > 0) {
-        const double* E = w.Ek + 9 * (j + 1);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (k % 3) + (rr % 3)] : 0.0;
-    } else {
-        const double* E = w.Ek + 9 * j;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) b[k] = (k / 3 == rr / 3) ? E[3 * (rr % 3) + (k % 3)] : 0.0;
-    }
-}
-
-// a -= b B'  (b = row r of the coupling factor B, a = row r of the diagonal block; only a[k], k <= r, is needed).
-// MFMA version: the wave parks B in LDS, accumulates the lower 16x16 tiles of B B' with v_mfma_f64_16x16x4_f64
-// (A operand = B[16ti + (l&15)][4ks + (l>>4)], B operand = the same rows of tile tj, i.e. B' ), writes the tiles to an
-// LDS scratch in the C/D layout (col = l&15, row = (l>>4) + 4*reg) and reads its own row back.  ~60 instructions of
-// loop body instead of 1296 unrolled readlane-FMA pairs (which alone overflowed the 64 KB instruction cache).
 typedef double d4 __attribute__((ext_vector_type(4)));
-#define SYRK_LDB (36 + 2)
-#define SYRK_LDU (48 + 2)
-#define SYRK_DINV (48 * SYRK_LDB + 48 * SYRK_LDU)  // [40]: 1 / d of the block whose coupling factor sits in the B area
-#define SYRK_LDS_DOUBLES (48 * SYRK_LDB + 48 * SYRK_LDU + 40)
-
-template <int NK>
-__device__ __forceinline__ void syrk_store_b(const double (&b)[NK], double* ldsB, int r) {
-    if (r < NK) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) ldsB[r * SYRK_LDB + k] = b[k];
-    }
-}
-
-// acc += X D^{-1} X'  (X in ldsB, 1/d in ldsD): the A operand is scaled on the fly, the B operand is X itself -- no square roots
-template <int NK>
-__device__ __forceinline__ void syrk_mfma_accumulate(d4 (&acc)[6], const double* ldsB, const double* ldsD, int lane) {
-    constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int ks = 0; ks < KS; ++ks) {
-        double op[3], os[3];
-        const double dk = ldsD[4 * ks + lk];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) op[t] = ldsB[(16 * t + li) * SYRK_LDB + 4 * ks + lk], os[t] = op[t] * dk;
-        int idx = 0;
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj, ++idx) acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(os[ti], op[tj], acc[idx], 0, 0, 0);
-    }
-}
-
-template <int NK>
-__device__ __forceinline__ void syrk_apply(double (&a)[NK], const d4 (&acc)[6], double* ldsU, int lane, int rr) {
-    constexpr int NT = (NK + 15) / 16;
-    const int li = lane & 15, lk = lane >> 4;
-    int idx = 0;
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = 0; tj <= ti; ++tj, ++idx)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ldsU[(16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li] = acc[idx][g];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int NK>
-__device__ __forceinline__ void syrk_rows(double (&a)[NK], const double (&b)[NK], double* ldsW, int lane, int rr) {
-    double* ldsB = ldsW;
-    double* ldsU = ldsW + 48 * SYRK_LDB;
-    syrk_store_b<NK>(b, ldsB, lane);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    d4 acc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] = d4{0, 0, 0, 0};
-    syrk_mfma_accumulate<NK>(acc, ldsB, ldsW + SYRK_DINV, lane);
-    syrk_apply<NK>(a, acc, ldsU, lane, rr);
-}
-
-// SQUARE-ROOT-FREE factorisation A = L D L' (L unit lower), right-looking, one row per lane: a[c] = L[r][c] for lanes r > c,
-// dinv = 1 / d_r of this lane's row.  Why not Cholesky: a dependent FP64 operation costs 32 cycles on this machine (measured:
-// 13.3 ns per dependent v_fma_f64), and the pivot path of a Cholesky column is rsqrt + two Newton steps + a multiply + the
-// update (nine dependent operations); here it is rcp + two Newton steps + multiply + update (seven), and -- the larger effect --
-// every triangular solve with the UNIT factor loses the multiplication by the inverse pivot from each of its dependent steps.
-template <int NK>
-__device__ __forceinline__ bool ldl_rows(double (&a)[NK], double& dinv) {
-    bool ok = true;
-    const int r = threadIdx.x & 63;
-    dinv = 1.0;
-#pragma unroll
-    for (int c = 0; c < NK; ++c) {
-        const double dcc = rl(a[c], c);
-        if (!(dcc > 0)) ok = false;
-        double inv = __builtin_amdgcn_rcp(dcc);  // v_rcp_f64 is good to 4.6e-8 (measured); ONE Newton step gives 2e-15, i.e. a
-        inv = fma(fma(-dcc, inv, 1.0), inv, inv);  // perturbation of the pivot at rounding level -- and two dependent operations
-        dinv = (r == c) ? inv : dinv;              // (64 cycles) less on every column's critical path than the second step
-        const double lc = a[c] * inv;  // L[r][c] (1 on the diagonal lane)
-#pragma unroll
-        for (int k = c + 1; k < NK; ++k) a[k] -= lc * rl(a[c], k);  // A[r][k] -= L[r][c] A[k][c]   (A[k][c] still unscaled in lane k)
-        a[c] = lc;
-    }
-    return ok;
-}
 
 template <int NK>
 __device__ __forceinline__ bool chol_rows(double (&a)[NK], double& dinv) {  // right-looking; a[c] = L[r][c] for lanes r >= c
-    bool ok = true;                                                           // dinv: 1 / L[r][r] of this lane's row
+    bool ok = true;                                                           // dinv: 1 / L[r][r] of this lane's row (tiled path)
     const int r = threadIdx.x & 63;
     dinv = 1.0;
 #pragma unroll
@@ -988,244 +877,100 @@ __device__ __forceinline__ bool chol_rows(double (&a)[NK], double& dinv) {  // r
     return ok;
 }
 
-#if QP_WAVES_PER_EU >= 4
-// ---- low-register variant (<= 128 VGPRs, so that two 512-thread workgroups share a CU): one block row per lane in
-// VGPRs at a time.  The factor L_jj is parked in LDS (row-major, in the scratch the rank-k update just vacated) and the
-// coupling solve x L_jj' = t reads L[c][k] as LDS broadcasts in dot-product form; t (a row of T_{j+1,j}, three non-zeros
-// out of Ek) is generated on the fly, so neither the coupling row nor the factor row is live next to x.
-#define WF_LDL (36 + 1)
+// ---- one chain of the twisted factorisation (round 3: knot_lds.inc, cross-lane traffic through LDS broadcasts) --------------------
+// Per knot j of the chain (the chain's previous knot jp = j - dir):
+//   S_j = T_j - X_j D_jp^-1 X_j'          X_j = T_{j,jp} L_jp^-T  (rows of block j), the rank-NK update on v_mfma_f64_16x16x4_f64
+//   S_j = L_j D_j L_j'                    kl_ldl: column images in LDS
+//   M_j = L_j^-T                          explicit (kl_row_times_LinvT): the substitutions are matrix-vector products with M_j, and
+//   X_jn = Cpl M_j                        the coupling factor towards the next knot costs three multiply-adds per entry
+// What a knot leaves in global memory for the substitutions is M_j (row r contiguous, entries k < r are zeros) and 1 / d_j: 5.5 KB of
+// triangle + diagonal instead of the two full blocks (L_j, X_j: 20.7 KB) of the round-2 formulation; X never leaves the LDS.
+#define KF_STRIDE(NK) ((NK) * (NK) + KL_I)  // doubles per knot in QpWs::Lf: M_j [NK][NK], then 1 / d_j
 
-template <int NK>
-__device__ __forceinline__ void syrk_tiles_lo(double* ldsW, int lane, bool accumulate) {
-    // U (+)= X D^{-1} X' (lower 16x16 tiles) with X in ldsW[0 .. 48*SYRK_LDB), 1/d in ldsW + SYRK_DINV, U in the scratch behind X;
-    // three MFMA tiles at a time (24 accumulator VGPRs), and no block row is live here: the caller loads it afterwards and
-    // subtracts its U row
-    const double* ldsB = ldsW;
-    const double* ldsD = ldsW + SYRK_DINV;
-    double* ldsU = ldsW + 48 * SYRK_LDB;
-    constexpr int NT = (NK + 15) / 16, KS = (NK + 3) / 4;
-    const int li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti) {
-        d4 acc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc[t] = d4{0, 0, 0, 0};
-        for (int ks = 0; ks < KS; ++ks) {
-            const double opi = ldsB[(16 * ti + li) * SYRK_LDB + 4 * ks + lk] * ldsD[4 * ks + lk];
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) {
-                const double opj = ldsB[(16 * tj + li) * SYRK_LDB + 4 * ks + lk];
-                acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(opi, opj, acc[tj], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int tj = 0; tj <= ti; ++tj)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                double* u = ldsU + (16 * ti + lk + 4 * g) * SYRK_LDU + 16 * tj + li;
-                *u = accumulate ? *u + acc[tj][g] : acc[tj][g];
-            }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// factor row a (lane rr) -> global Lf block [k][r] and LDS row-major copy + reciprocal diagonal
-template <int NK>
-__device__ __forceinline__ void park_factor(const double (&a)[NK], double dinv, double* L0, double* ldsL, double* ldsInv, int r,
-                                            bool act) {
-    if (act) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);  // unit lower factor, 1/d on the diagonal
-            ldsL[r * WF_LDL + k] = a[k];
-        }
-        ldsInv[r] = dinv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// x <- t L^{-T} for the coupling row t of lane rr towards the next block of the chain (coupling_row)
-template <int NK>
-__device__ __forceinline__ void coupling_solve_lo(const QpWs& w, int j, int dir, int rr, const double* ldsL, const double* ldsInv,
-                                                  double (&x)[NK]) {
+// coefficients of row rr of the coupling block between knot j and the next knot of the chain: T_{j+dir,j}[rr][3g + q], g = rr / 3
+// (T_{j+1,j} = blockdiag(E_{knot j+1}'), T_{j-1,j} = T_{j,j-1}'; see assemble_blocks)
+__device__ __forceinline__ void coupling_coef(const QpWs& w, int j, int dir, int rr, double& e0, double& e1, double& e2) {
     const double* E = w.Ek + 9 * (dir > 0 ? j + 1 : j);
-    const double e0 = dir > 0 ? E[rr % 3] : E[3 * (rr % 3)], e1 = dir > 0 ? E[3 + rr % 3] : E[3 * (rr % 3) + 1],
-                 e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
-    const int c0 = 3 * (rr / 3);  // the row's three non-zeros sit in columns c0 .. c0+2
+    e0 = dir > 0 ? E[rr % 3] : E[3 * (rr % 3)], e1 = dir > 0 ? E[3 + rr % 3] : E[3 * (rr % 3) + 1],
+    e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
+}
+
+// row r of M_j and 1 / d_j -> QpWs::Lf (16 bytes per lane and store instruction: the store path of a CU is issue bound)
+template <int NK>
+__device__ __forceinline__ void store_knot_factor(const double (&m)[NK], const kl_lds* I, double* Mg, int r, bool act) {
+    if (act) {
+        double* row = Mg + (size_t)r * NK;
+        if ((NK & 1) == 0) {
 #pragma unroll
-    for (int c = 0; c < NK; ++c) {
-        double s0 = (c == c0) ? e0 : ((c == c0 + 1) ? e1 : ((c == c0 + 2) ? e2 : 0.0)), s1 = 0.0;
+            for (int k = 0; k < NK; k += 2) *(kl_d2*)(row + k) = kl_d2{m[k], m[k + 1]};
+        } else {
 #pragma unroll
-        for (int k = 0; k < c; ++k) {
-            if (k & 1)
-                s1 -= x[k] * ldsL[c * WF_LDL + k];
-            else
-                s0 -= x[k] * ldsL[c * WF_LDL + k];
+            for (int k = 0; k < NK; ++k) row[k] = m[k];
         }
-        x[c] = s0 + s1;  // L is unit lower: no pivot
+        Mg[NK * NK + r] = I[r];
     }
 }
 
+// the diagonal block of one knot: S = T_j (- U), factorised, M = L^-T in MX and in global memory.  Returns false on a non-positive pivot.
+template <int NK>
+__device__ __forceinline__ bool knot_block(const QpWs& w, int j, bool minus_u, kl_lds* base, int r, bool act, int rr) {
+    using A = KlArea<NK>;
+    kl_lds *C = base + A::C, *MX = base + A::MX, *I = base + A::I, *U = base + A::C;
+    double a[NK];
+    const double* Tg = w.Td + (size_t)j * NK * NK;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access; only k <= r was assembled and is used
+    if (minus_u) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] -= U[rr * KL_LDU + k];
+        kl_sync();
+    }
+    const bool ok = kl_ldl<NK>(a, C, I, r, act);
+    double m[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) m[k] = (k == r) ? 1.0 : 0.0;
+    kl_row_times_LinvT<NK>(m, C, I);
+    kl_store_rows<NK>(m, MX, r, act);
+    store_knot_factor<NK>(m, I, w.Lf + (size_t)j * KF_STRIDE(NK), r, act);
+    return ok;
+}
+
+// one chain: blocks j0, j0+dir, ... (count of them).  On return the chain's LDS area holds the coupling factor X towards the middle
+// block (MX) and the reciprocal pivots of its last block (I): wave_factor_mid reads both chains' areas.
 template <int NK>
 __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt) {
+    using A = KlArea<NK>;
+    kl_lds* base = (kl_lds*)ldsW;
+    kl_lds *MX = base + A::MX, *I = base + A::I, *U = base + A::C;
     const int r = threadIdx.x & 63;
     const bool act = r < NK;
     const int rr = act ? r : 0;
-    double* ldsB = ldsW;
-    double* ldsL = ldsW + 48 * SYRK_LDB;  // overlays the U tiles of the rank-k update
-    double* ldsInv = ldsW + SYRK_DINV;    // 1/d of the block just factorised: scales the next step's rank-k update
     bool ok = true;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
-        if (i > 0) syrk_tiles_lo<NK>(ldsW, r, false);
-        double a[NK];
+        if (i > 0) kl_syrk<NK>(MX, I, U, r, false);
         if (cnt) wait_blocks(cnt, i);
-        const double* Tg = w.Td + (size_t)j * NK * NK;
-        const double* ldsU = ldsW + 48 * SYRK_LDB;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
-        if (i > 0) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];  // k > r reads the (unused) upper triangle
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        double dinv;
-        if (!ldl_rows<NK>(a, dinv)) ok = false;
-        double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
-        park_factor<NK>(a, dinv, L0, ldsL, ldsInv, r, act);
-        {
-            double x[NK];
-            coupling_solve_lo<NK>(w, j, dir, rr, ldsL, ldsInv, x);
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = x[k], ldsB[r * SYRK_LDB + k] = x[k];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        if (!knot_block<NK>(w, j, i > 0, base, r, act, rr)) ok = false;
+        double e0, e1, e2, x[NK];
+        coupling_coef(w, j, dir, rr, e0, e1, e2);
+        kl_coupling_rows<NK>(x, MX, r, act, e0, e1, e2);
     }
     return ok;
 }
 
+// the middle block collects both Schur complements (the chains' areas: ldsL = left chain = this wave's own area, ldsR = right chain)
 template <int NK>
-__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW, int* cnt, int cnt_idx) {
+__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsL, double* ldsR, int* cnt, int cnt_idx) {
+    using A = KlArea<NK>;
+    kl_lds *bl = (kl_lds*)ldsL, *br = (kl_lds*)ldsR;
     const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
     const bool act = r < NK;
     const int rr = act ? r : 0;
     int nsy = 0;
-    for (int side = 0; side < 2; ++side) {
-        const int jn = side == 0 ? mid - 1 : mid + 1;
-        if (jn < 0 || jn >= d.nj) continue;
-        const double* Lm = w.Lf + (size_t)jn * 2 * NK * NK;
-        const double* Bm = Lm + NK * NK;
-        if (act) {
-            for (int k = 0; k < NK; ++k) ldsW[r * SYRK_LDB + k] = Bm[k * NK + r];
-            ldsW[SYRK_DINV + r] = Lm[r * NK + r];  // 1/d of block jn
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        syrk_tiles_lo<NK>(ldsW, r, nsy > 0);
-        nsy++;
-    }
-    double a[NK];
+    if (mid > 0) kl_syrk<NK>(bl + A::MX, bl + A::I, bl + A::C, r, false), nsy++;
+    if (mid + 1 < d.nj) kl_syrk<NK>(br + A::MX, br + A::I, bl + A::C, r, nsy > 0), nsy++;
     if (cnt) wait_blocks(cnt, cnt_idx);
-    const double* Tg = w.Td + (size_t)mid * NK * NK;
-    const double* ldsU = ldsW + 48 * SYRK_LDB;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
-    if (nsy > 0) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) a[k] -= ldsU[rr * SYRK_LDU + k];
-    }
-    double dinv;
-    if (!ldl_rows<NK>(a, dinv)) return false;
-    double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
-    if (act) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);
-    }
-    return true;
+    return knot_block<NK>(w, mid, nsy > 0, bl, r, act, rr);
 }
-#else
-// one chain: blocks j0, j0+dir, ... (count of them)
-template <int NK>
-__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt) {
-    const int r = threadIdx.x & 63;
-    const bool act = r < NK;
-    const int rr = act ? r : 0;
-    double a[NK], b[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) b[k] = 0;
-    for (int i = 0, j = j0; i < count; ++i, j += dir) {
-        if (cnt) wait_blocks(cnt, i);
-        const double* Tg = w.Td + (size_t)j * NK * NK;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access
-        if (i > 0) syrk_rows<NK>(a, b, ldsW, r, rr);  // a -= row of X D^{-1} X' of the previous block (its 1/d sits in ldsW + SYRK_DINV)
-        double dinv;
-        if (!ldl_rows<NK>(a, dinv)) return false;
-        double* L0 = w.Lf + (size_t)j * 2 * NK * NK;
-        if (act) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);  // unit lower factor, 1/d on the diagonal
-            ldsW[SYRK_DINV + r] = dinv;
-        }
-        // coupling towards the next block of the chain (the last one couples to the middle block): b <- Tn L_jj^{-T}, L unit:
-        // one dependent multiply-add per column
-        coupling_row<NK>(w, j, dir, rr, b);
-#pragma unroll
-        for (int c = 0; c < NK; ++c) {
-            const double xc = b[c];
-#pragma unroll
-            for (int k = c + 1; k < NK; ++k) b[k] -= xc * rl(a[c], k);
-        }
-        if (act) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) L0[NK * NK + k * NK + r] = b[k];
-        }
-    }
-    return true;
-}
-
-template <int NK>
-__device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, double* ldsW, int* cnt, int cnt_idx) {
-    const int r = threadIdx.x & 63, mid = twist_mid(d.nj);
-    const bool act = r < NK;
-    const int rr = act ? r : 0;
-    double a[NK], b[NK];
-    if (cnt) wait_blocks(cnt, cnt_idx);
-    const double* Tg = w.Td + (size_t)mid * NK * NK;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
-    if (mid > 0) {
-        const double* Lm = w.Lf + (size_t)(mid - 1) * 2 * NK * NK;
-        const double* Bm = Lm + NK * NK;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) b[k] = Bm[k * NK + rr];
-        if (act) ldsW[SYRK_DINV + r] = Lm[r * NK + r];  // 1/d of block mid-1
-        syrk_rows<NK>(a, b, ldsW, r, rr);
-    }
-    if (mid + 1 < d.nj) {
-        const double* Lm = w.Lf + (size_t)(mid + 1) * 2 * NK * NK;
-        const double* Cm = Lm + NK * NK;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) b[k] = Cm[k * NK + rr];
-        if (act) ldsW[SYRK_DINV + r] = Lm[r * NK + r];
-        syrk_rows<NK>(a, b, ldsW, r, rr);
-    }
-    double dinv;
-    if (!ldl_rows<NK>(a, dinv)) return false;
-    double* L0 = w.Lf + (size_t)mid * 2 * NK * NK;
-    if (act) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) L0[k * NK + r] = k < r ? a[k] : (k == r ? dinv : 0.0);
-    }
-    return true;
-}
-
-#endif
 
 // whole twisted factorisation; every thread of the workgroup calls it.  flag: LDS int.
 // asmb != nullptr: the knot blocks T_j are ASSEMBLED HERE, by the waves that do not run a chain, in the order the chains consume
@@ -1236,12 +981,13 @@ template <int NK, int ROLE>
 __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds, const AsmArgs* asmb) {
     const int wave = ROLE == 0 ? (threadIdx.x >> 6) & 1 : 2, mid = twist_mid(d.nj);
     const int nl = mid, nr = d.nj - 1 - mid, SF = nl > nr ? nl : nr;
-    int* cnt = (int*)(lds + 2 * SYRK_LDS_DOUBLES);  // [SF + 1]
+    constexpr int AREA = KlArea<NK>::SIZE;    // one chain wave's LDS area (knot_lds.inc)
+    int* cnt = (int*)(lds + 2 * AREA);  // [SF + 1]
     if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
     bool ok = true;
-    // rows >= NK of the LDS copy of B are never written: clear them once (they only feed unused tile entries)
-    for (int i = threadIdx.x; i < 2 * SYRK_LDS_DOUBLES + 64; i += QP_THREADS) lds[i] = 0.0;
+    // rows >= NK of the X images are never written by a row's own lane: clear them once (they only feed unused tile entries)
+    for (int i = threadIdx.x; i < 2 * AREA + 64; i += QP_THREADS) lds[i] = 0.0;
     __syncthreads();
     int* cw = asmb ? cnt : nullptr;
     // The chain waves issue one dependent instruction every ~32 cycles; whenever the SIMD's arbiter makes one of them queue
@@ -1250,7 +996,7 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     if (ROLE == 0) {
         __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);
         if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cw);
-        if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + SYRK_LDS_DOUBLES, cw);
+        if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + AREA, cw);
         if (wave == 1) __builtin_amdgcn_s_setprio(0);
     }
     if (ROLE == 1 && asmb) {
@@ -1276,7 +1022,7 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     __syncthreads();
     if (*flag) return false;
     if (ROLE == 0 && wave == 0) {
-        if (!wave_factor_mid<NK>(d, w, lds, cw, SF) && threadIdx.x == 0) *flag = 1;
+        if (!wave_factor_mid<NK>(d, w, lds, lds + AREA, cw, SF) && threadIdx.x == 0) *flag = 1;
         __builtin_amdgcn_s_setprio(0);
     }
     __threadfence_block();
@@ -1284,201 +1030,206 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     return *flag == 0;
 }
 
-// Substitutions T du = rhs for the twisted factorisation, factor blocks STAGED THROUGH LDS: waves 2.. prefetch the
-// blocks of step s+1 (coalesced global reads into a double buffer) while waves 0 / 1 run step s of the left / right
-// chain out of LDS with a row (forward) or a column (backward) of each block in VGPRs.  rhs lives in LDS throughout.
-// A stage holds, per chain, the diagonal factor PACKED (lower triangle, column-major: element (r,k), r >= k, at
-// k*NK - k(k-1)/2 + r - k) and the full coupling block (element (r,k) at k*(NK+1) + r): 2 x (2*DG + 2*BLK) + nj*NK
-// doubles = 74 KB for NK = 36, so that two 256-thread workgroups share one CU's LDS.
-// ROLE: 0 = compiled for the two chain waves, 1 = for the staging waves (2..), -1 = for all (one function).  The two roles are
-// separate __noinline__ functions (solve_entry): the staging waves need a dozen registers, and a function that uses only caller-saved
-// VGPRs has no prologue -- six of the eight waves stop writing 48 callee-saved registers to scratch and reading them back per call.
+// Substitutions T du = rhs for the twisted factorisation (round 3: matrix-vector products with the explicit M_j = L_j^-T instead of
+// 36-step dependent triangular solves).  With X_j = T_{j,jp} M_jp (jp = the chain's previous knot, never stored):
+//   forward   r'  = rhs_j - T_{j,jp} v_jp          (3x3-block sparse)         y = M_j' r'      z_j = D_j^-1 y      v_j = M_j z_j
+//   backward  w   = T_{jn,j}' x_jn                 (jn = next knot towards the middle)
+//             x_j = M_j (z_j - D_j^-1 M_j' w)
+// i.e. two dense products with the SAME staged matrix per chain step (one by columns, one by rows), vectors broadcast from LDS.
+// The knots' M_j are STAGED THROUGH LDS: waves 2.. prefetch the blocks of step s + QP_STAGE_BUFS - 1 (coalesced global reads) while
+// waves 0 / 1 run step s of the left / right chain.  rhs -> z -> x lives in LDS throughout (vec).
+// ROLE: 0 = compiled for the two chain waves, 1 = for the staging waves (2..): two __noinline__ functions (solve_entry_*), so that the
+// staging waves -- a dozen registers -- have no prologue saving callee-saved VGPRs.
+#define KS_CH 12  // k-chunk of the products: loads of the next chunk are issued ahead of the arithmetic of the current one
+
+// sum_k Mst[k][rr] * b[k]  (column rr of the staged matrix: consecutive lanes read consecutive addresses)
+template <int NK>
+__device__ __forceinline__ double kl_matvec_cols(const kl_lds* Mst, const kl_lds* b, int rr) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    double mc[2][KS_CH];
+    kl_d2 bc[2][KS_CH / 2];
+#pragma unroll
+    for (int q = 0; q < KS_CH; ++q)
+        if (q < NK) mc[0][q] = Mst[q * KL_LD + rr];
+#pragma unroll
+    for (int q = 0; q < KS_CH / 2; ++q)
+        if (2 * q < NK) bc[0][q] = *(const kl_lds2*)(b + 2 * q);
+#pragma unroll
+    for (int ch = 0; ch * KS_CH < NK; ++ch) {
+        const int kn = (ch + 1) * KS_CH;
+#pragma unroll
+        for (int q = 0; q < KS_CH; ++q)
+            if (kn + q < NK) mc[(ch + 1) & 1][q] = Mst[(kn + q) * KL_LD + rr];
+#pragma unroll
+        for (int q = 0; q < KS_CH / 2; ++q)
+            if (kn + 2 * q < NK) bc[(ch + 1) & 1][q] = *(const kl_lds2*)(b + kn + 2 * q);
+#pragma unroll
+        for (int q = 0; q < KS_CH; q += 4) {
+            const int k = ch * KS_CH + q;
+            if (k < NK) s0 += mc[ch & 1][q] * bc[ch & 1][q / 2][0];
+            if (k + 1 < NK) s1 += mc[ch & 1][q + 1] * bc[ch & 1][q / 2][1];
+            if (k + 2 < NK) s2 += mc[ch & 1][q + 2] * bc[ch & 1][q / 2 + 1][0];
+            if (k + 3 < NK) s3 += mc[ch & 1][q + 3] * bc[ch & 1][q / 2 + 1][1];
+        }
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// sum_k Mst[rr][k] * b[k]  (row rr of the staged matrix: 16-byte loads per lane, rows KL_LD apart are conflict free)
+template <int NK>
+__device__ __forceinline__ double kl_matvec_rows(const kl_lds* Mst, const kl_lds* b, int rr) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const kl_lds* row = Mst + rr * KL_LD;
+    kl_d2 mc[2][KS_CH / 2], bc[2][KS_CH / 2];
+#pragma unroll
+    for (int q = 0; q < KS_CH / 2; ++q)
+        if (2 * q < NK) mc[0][q] = *(const kl_lds2*)(row + 2 * q), bc[0][q] = *(const kl_lds2*)(b + 2 * q);
+#pragma unroll
+    for (int ch = 0; ch * KS_CH < NK; ++ch) {
+        const int kn = (ch + 1) * KS_CH;
+#pragma unroll
+        for (int q = 0; q < KS_CH / 2; ++q)
+            if (kn + 2 * q < NK) mc[(ch + 1) & 1][q] = *(const kl_lds2*)(row + kn + 2 * q), bc[(ch + 1) & 1][q] = *(const kl_lds2*)(b + kn + 2 * q);
+#pragma unroll
+        for (int q = 0; q < KS_CH; q += 4) {
+            const int k = ch * KS_CH + q;
+            if (k < NK) s0 += mc[ch & 1][q / 2][0] * bc[ch & 1][q / 2][0];
+            if (k + 1 < NK) s1 += mc[ch & 1][q / 2][1] * bc[ch & 1][q / 2][1];
+            if (k + 2 < NK) s2 += mc[ch & 1][q / 2 + 1][0] * bc[ch & 1][q / 2 + 1][0];
+            if (k + 3 < NK) s3 += mc[ch & 1][q / 2 + 1][1] * bc[ch & 1][q / 2 + 1][1];
+        }
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+template <int NK>
+struct KsLayout {  // doubles
+    static constexpr int SM = NK * KL_LD, SCH = SM + KL_I, STG = 2 * SCH;  // a stage: left chain (M, 1/d), right chain (M, 1/d)
+    static constexpr int VECS = 6 * KL_I;                                  // per chain: A (r' / w), Z (z / u), V (v / x of the block just done)
+};
+
 template <int NK, int ROLE>
 __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
-    constexpr int LDP = NK + 1, BLK = NK * LDP, DG = (NK * (NK + 1) / 2 + 7) & ~7, STG = 2 * DG + 2 * BLK;
-    // stage layout: [0, DG) left diag, [DG, DG+BLK) left coupling, [DG+BLK, 2DG+BLK) right diag, [2DG+BLK, STG) right coupling
-    constexpr int O_LD = 0, O_LO = DG, O_RD = DG + BLK, O_RO = 2 * DG + BLK;
+    using KS = KsLayout<NK>;
+    constexpr int STG = KS::STG, SCH = KS::SCH, SM = KS::SM;
     const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
     const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
-    // QP_STAGE_BUFS stage buffers: the blocks of step s + QP_STAGE_BUFS - 1 are fetched while step s runs.  With the unit-factor
-    // steps (~1 us) a prefetch distance of one step no longer covers a global-memory round trip: three buffers in the
-    // one-workgroup-per-CU build (106 KB of LDS), two in the two-per-CU build (its second workgroup covers the wait)
-    double* vec = lds + QP_STAGE_BUFS * STG;  // nj*NK
+    double* vec = lds + QP_STAGE_BUFS * STG;           // nj*NK: rhs -> z -> x
+    double* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KL_I]
     for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
+    for (int i = tid; i < KS::VECS; i += QP_THREADS) small[i] = 0.0;
     // block indices handled at step s by the left / right wave (-1: idle)
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
     auto right_j = [&](int s) { return s < SF ? (s - (SF - nr) >= 0 ? nj - 1 - (s - (SF - nr)) : -1) : (s == SF ? -1 : (mid + 1 + (s - SF - 1) <= nj - 1 ? mid + 1 + (s - SF - 1) : -1)); };
-    auto copy_blk = [&](const double* src, double* dst, int t0, int nt) {
-        // all loads first, then the LDS stores (element (r,k) stays at k*LDP + r): keeps up to QP_STAGE_LOADS loads in flight per lane
-        double tmp[QP_STAGE_LOADS];
-#pragma unroll
-        for (int u = 0; u < QP_STAGE_LOADS; ++u) {
-            const int it = t0 + u * nt;
-            tmp[u] = it < NK * NK ? src[it] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < QP_STAGE_LOADS; ++u) {
-            const int it = t0 + u * nt;
-            if (it < NK * NK) dst[(it / NK) * LDP + it % NK] = tmp[u];
-        }
-        for (int it = t0 + QP_STAGE_LOADS * nt; it < NK * NK; it += nt) dst[(it / NK) * LDP + it % NK] = src[it];
-    };
-    auto copy_diag = [&](const double* src, double* dst, int t0, int nt) {  // lower triangle of src[k*NK + r] -> packed
-        for (int base = t0; base < NK * NK; base += QP_STAGE_LOADS * nt) {  // QP_STAGE_LOADS loads in flight per lane, then the LDS stores
+    auto copy_knot = [&](int j, double* dst, int t0, int nt) {  // M_j rows -> rows of KL_LD, then 1 / d_j; QP_STAGE_LOADS loads in flight per lane
+        const double* src = w.Lf + (size_t)j * KF_STRIDE(NK);
+        constexpr int TOT = NK * NK + NK;
+        for (int base = t0; base < TOT; base += QP_STAGE_LOADS * nt) {
             double tmp[QP_STAGE_LOADS];
 #pragma unroll
             for (int u = 0; u < QP_STAGE_LOADS; ++u) {
                 const int it = base + u * nt;
-                tmp[u] = it < NK * NK && it % NK >= it / NK ? src[it] : 0.0;  // the upper triangle (zeros) is not fetched
+                tmp[u] = it < TOT ? src[it] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < QP_STAGE_LOADS; ++u) {
-                const int it = base + u * nt, k = it / NK, r = it % NK;
-                if (it < NK * NK && r >= k) dst[k * NK - k * (k - 1) / 2 + r - k] = tmp[u];
+                const int it = base + u * nt;
+                if (it < NK * NK)
+                    dst[(it / NK) * KL_LD + it % NK] = tmp[u];
+                else if (it < TOT)
+                    dst[SM + it - NK * NK] = tmp[u];
             }
         }
     };
     auto stage = [&](int s, double* buf, int t0, int nt) {
         const int jl = left_j(s), jr = right_j(s);
-        if (s == SF) {  // middle: L_mid, B_mid, C_mid
-            copy_diag(w.Lf + (size_t)mid * 2 * NK * NK, buf + O_LD, t0, nt);
-            if (mid > 0) copy_blk(w.Lf + (size_t)(mid - 1) * 2 * NK * NK + NK * NK, buf + O_LO, t0, nt);
-            if (mid + 1 < nj) copy_blk(w.Lf + (size_t)(mid + 1) * 2 * NK * NK + NK * NK, buf + O_RO, t0, nt);
-            return;
-        }
-        const bool fwd = s < SF;
-        if (jl >= 0) {
-            copy_diag(w.Lf + (size_t)jl * 2 * NK * NK, buf + O_LD, t0, nt);
-            // forward: B_jl = Lf[jl-1][1] (rows of block jl); backward: B_{jl+1} = Lf[jl][1]
-            if (fwd ? jl > 0 : true) copy_blk(w.Lf + (size_t)(fwd ? jl - 1 : jl) * 2 * NK * NK + NK * NK, buf + O_LO, t0, nt);
-        }
-        if (jr >= 0) {
-            copy_diag(w.Lf + (size_t)jr * 2 * NK * NK, buf + O_RD, t0, nt);
-            // forward: C_jr = Lf[jr+1][1] (rows of block jr); backward: C_{jr-1} = Lf[jr][1]
-            if (fwd ? jr + 1 < nj : true) copy_blk(w.Lf + (size_t)(fwd ? jr + 1 : jr) * 2 * NK * NK + NK * NK, buf + O_RO, t0, nt);
-        }
+        if (jl >= 0) copy_knot(jl, buf, t0, nt);
+        if (jr >= 0) copy_knot(jr, buf + SCH, t0, nt);
     };
     for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG, tid, QP_THREADS);
     __syncthreads();
-    const int wave = ROLE == 0 ? (tid >> 6) & 1 : (ROLE == 1 ? 2 : tid >> 6), r = tid & 63;  // (role 1 only needs "wave >= 2")
-    const int rr = r < NK ? r : 0;
-    // row rr of the packed factor: a[k] = L[rr][k], k <= rr; column rr: a[k] = L[k][rr], k >= rr
-#define DG_ROW(dg, k) ((k) < rr ? (dg)[(k) * NK - (k) * ((k) - 1) / 2 + rr - (k)] : 0.0)
-#define DG_COL(dg, k) ((k) > rr ? (dg)[rr * NK - rr * (rr - 1) / 2 + (k) - rr] : 0.0)
-    // products with a coupling block: four partial sums (a single accumulator would be a chain of 36 dependent FP64 operations, 32
-    // cycles each)
-    auto dot_rows = [&](const double* blk_col0, int stride_k, const double* xs) {  // sum_k blk[k*stride] * xs[k], xs in LDS
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-QP_DOT_UNROLL
-        for (int k = 0; k < NK; k += 4) {
-            s0 += blk_col0[k * stride_k] * xs[k];
-            if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * xs[k + 1];
-            if (k + 2 < NK) s2 += blk_col0[(k + 2) * stride_k] * xs[k + 2];
-            if (k + 3 < NK) s3 += blk_col0[(k + 3) * stride_k] * xs[k + 3];
-        }
-        return (s0 + s1) + (s2 + s3);
-    };
-    auto dot_lanes = [&](const double* blk_col0, int stride_k, double xv) {  // same with xs[k] = lane k's xv
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-QP_DOT_UNROLL
-        for (int k = 0; k < NK; k += 4) {
-            s0 += blk_col0[k * stride_k] * rl(xv, k);
-            if (k + 1 < NK) s1 += blk_col0[(k + 1) * stride_k] * rl(xv, k + 1);
-            if (k + 2 < NK) s2 += blk_col0[(k + 2) * stride_k] * rl(xv, k + 2);
-            if (k + 3 < NK) s3 += blk_col0[(k + 3) * stride_k] * rl(xv, k + 3);
-        }
-        return (s0 + s1) + (s2 + s3);
-    };
-    // The blocks are factorised as L D L' with L UNIT lower (1/d sits on the diagonal of the packed factor): a step of a
-    // triangular solve is one readlane and one multiply-add.  With X_j = T_{j,jp} L_jp^{-T} (the stored coupling factor):
-    //   forward   y_j = L_j^{-1} (r_j - X_j z_jp),  z_j = D_j^{-1} y_j          backward   x_j = L_j^{-T} (z_j - D_j^{-1} X_jn' x_jn)
-    // factor entries of a dependent solve: preloaded into registers where the budget allows (256-VGPR build: an LDS round trip per
-    // dependent step would triple the step), read where they are used otherwise (128-VGPR build: preloading spills)
-#if QP_WAVES_PER_EU >= 4
-#define LROW_DECL
-#define LROW_LOAD(expr_of_c)
-#define LROW(c, expr) (expr)
-#else
-#define LROW_DECL double lrow[NK]
-#define LROW_LOAD(expr_of_c)                                 \
-    _Pragma("unroll") for (int c = 0; c < NK; ++c) lrow[c] = (expr_of_c)
-#define LROW(c, expr) lrow[c]
-#endif
-    double prev = 0;  // this chain's previous vector (z forward, x backward), element r
+    const int wave = ROLE == 0 ? (tid >> 6) & 1 : 2, r = tid & 63;  // (role 1 only needs "wave >= 2")
+    const bool act = r < NK;
+    const int rr = act ? r : 0, g3 = 3 * (rr / 3), r3 = rr % 3;
+    const int rs = act ? r : KL_I - 1;  // lanes >= NK write the padding slot of the small vectors
     if (wave < 2) __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);  // see twisted_factor
     for (int s = 0; s < nsteps; ++s) {
         double* buf = lds + (s % QP_STAGE_BUFS) * STG;
-        if (ROLE == 1 || (ROLE < 0 && wave >= 2)) {
+        if (ROLE == 1) {
             const int sp = s + QP_STAGE_BUFS - 1;
             if (sp < nsteps) stage(sp, lds + (sp % QP_STAGE_BUFS) * STG, tid - 128, QP_THREADS - 128);
-        } else if (ROLE == 1) {
         } else if (s == SF) {
-            if (wave == 0) {  // middle block: forward with both neighbours, then backward
+            if (wave == 0) {  // middle block: forward with both neighbours' v, then backward; x_mid goes to both chains' V
+                const kl_lds* Mst = (const kl_lds*)buf;
+                kl_lds *A0 = (kl_lds*)small, *Z0 = A0 + KL_I, *V0 = A0 + 2 * KL_I, *V1 = A0 + 5 * KL_I;
                 double v = vec[mid * NK + rr];
-                const double* dgm = buf + O_LD;
-                if (mid > 0) v -= dot_rows(buf + O_LO + rr, LDP, vec + (mid - 1) * NK);
-                if (mid + 1 < nj) v -= dot_rows(buf + O_RO + rr, LDP, vec + (mid + 1) * NK);
-                const double inv = dgm[rr * NK - rr * (rr - 1) / 2];  // 1 / d_rr
-                LROW_DECL;
-                LROW_LOAD(DG_ROW(dgm, c));
-QP_SOLVE_UNROLL
-                for (int c = 0; c < NK; ++c) {
-                    const double xc = rl(v, c);
-                    v -= LROW(c, DG_ROW(dgm, c)) * xc;  // 0 for lanes r <= c: no select on the dependent chain
+                if (mid > 0) {
+                    double e0, e1, e2;
+                    coupling_coef(w, mid - 1, +1, rr, e0, e1, e2);
+                    v -= e0 * V0[g3] + e1 * V0[g3 + 1] + e2 * V0[g3 + 2];
                 }
-                v *= inv;
-                LROW_LOAD(DG_COL(dgm, c));
-QP_SOLVE_UNROLL
-                for (int c = NK - 1; c >= 0; --c) {
-                    const double xc = rl(v, c);
-                    v -= LROW(c, DG_COL(dgm, c)) * xc;
+                if (mid + 1 < nj) {
+                    double e0, e1, e2;
+                    coupling_coef(w, mid + 1, -1, rr, e0, e1, e2);
+                    v -= e0 * V1[g3] + e1 * V1[g3 + 1] + e2 * V1[g3 + 2];
                 }
-                if (r < NK) vec[mid * NK + r] = v;
+                A0[rs] = v;
+                kl_sync();
+                const double z = Mst[SM + rr] * kl_matvec_cols<NK>(Mst, A0, rr);
+                Z0[rs] = z;
+                kl_sync();
+                const double x = kl_matvec_rows<NK>(Mst, Z0, rr);
+                kl_sync();
+                V0[rs] = x, V1[rs] = x;
+                if (act) vec[mid * NK + r] = x;
             }
         } else {
             const bool fwd = s < SF;
             const int jb = wave == 0 ? left_j(s) : right_j(s);
             if (jb >= 0) {
-                const double* dgp = buf + (wave == 0 ? O_LD : O_RD);
-                const double* bl = buf + (wave == 0 ? O_LO : O_RO);
-                double v = vec[jb * NK + rr];
-                const bool first_bwd = !fwd && s == SF + 1;  // neighbour solution comes from the middle block (in LDS)
-                const bool has_nb = fwd ? (wave == 0 ? jb > 0 : jb + 1 < nj) : true;
-                // the factor entries are read from LDS where they are used (no 36-double row held in VGPRs: the loads do
-                // not depend on the chain and the scheduler hoists as many as the register budget allows)
-                const double inv = dgp[rr * NK - rr * (rr - 1) / 2];  // 1 / d_rr
-                LROW_DECL;
+                const int dir = wave == 0 ? +1 : -1;  // direction of this chain's elimination
+                const kl_lds* Mst = (const kl_lds*)(buf + (wave == 0 ? 0 : SCH));
+                kl_lds *A = (kl_lds*)small + (wave == 0 ? 0 : 3 * KL_I), *Z = A + KL_I, *V = A + 2 * KL_I;
+                const double dinv = Mst[SM + rr];
                 if (fwd) {
-                    LROW_LOAD(DG_ROW(dgp, c));
-                    if (has_nb) v -= dot_lanes(bl + rr, LDP, prev);
-QP_SOLVE_UNROLL
-                    for (int c = 0; c < NK; ++c) {
-                        const double xc = rl(v, c);
-                        v -= LROW(c, DG_ROW(dgp, c)) * xc;
+                    double v = vec[jb * NK + rr];
+                    const bool has_prev = wave == 0 ? jb > 0 : jb + 1 < nj;
+                    if (has_prev) {  // r' = rhs_j - T_{j,jp} v_jp
+                        double e0, e1, e2;
+                        coupling_coef(w, jb - dir, dir, rr, e0, e1, e2);
+                        v -= e0 * V[g3] + e1 * V[g3 + 1] + e2 * V[g3 + 2];
                     }
-                    v *= inv;  // z_j
+                    kl_sync();
+                    A[rs] = v;
+                    kl_sync();
+                    const double z = dinv * kl_matvec_cols<NK>(Mst, A, rr);
+                    Z[rs] = z;
+                    if (act) vec[jb * NK + r] = z;
+                    kl_sync();
+                    const double vj = kl_matvec_rows<NK>(Mst, Z, rr);
+                    kl_sync();
+                    V[rs] = vj;
                 } else {
-                    LROW_LOAD(DG_COL(dgp, c));
-                    const double t = first_bwd ? dot_rows(bl + rr * LDP, 1, vec + mid * NK) : dot_lanes(bl + rr * LDP, 1, prev);
-                    v -= inv * t;
-QP_SOLVE_UNROLL
-                    for (int c = NK - 1; c >= 0; --c) {
-                        const double xc = rl(v, c);
-                        v -= LROW(c, DG_COL(dgp, c)) * xc;
-                    }
+                    // w = T_{jn,j}' x_jn: column rr of the 3x3 block of its (agent, dim) group, rows g3 .. g3+2 (x_jn sits in V)
+                    const double* E = w.Ek + 9 * (dir > 0 ? jb + 1 : jb);
+                    const double c0 = dir > 0 ? E[3 * r3] : E[r3], c1 = dir > 0 ? E[3 * r3 + 1] : E[3 + r3], c2 = dir > 0 ? E[3 * r3 + 2] : E[6 + r3];
+                    const double wv = c0 * V[g3] + c1 * V[g3 + 1] + c2 * V[g3 + 2];
+                    kl_sync();
+                    A[rs] = wv;
+                    kl_sync();
+                    const double u = vec[jb * NK + rr] - dinv * kl_matvec_cols<NK>(Mst, A, rr);
+                    Z[rs] = u;
+                    kl_sync();
+                    const double x = kl_matvec_rows<NK>(Mst, Z, rr);
+                    kl_sync();
+                    V[rs] = x;
+                    if (act) vec[jb * NK + r] = x;
                 }
-                prev = v;
-                if (r < NK) vec[jb * NK + r] = v;
             }
         }
         __syncthreads();
     }
-#undef LROW_DECL
-#undef LROW_LOAD
-#undef LROW
-#undef DG_ROW
-#undef DG_COL
     if (wave < 2) __builtin_amdgcn_s_setprio(0);
     for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
     __threadfence_block();
@@ -2211,10 +1962,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     double flops = 0, rows_swept = 0, row_bytes = 0;
     // ALGORITHMIC HBM bytes of one interior-point iteration (the numerator of the HBM roofline): per row the three
     // sweeps read (s, z) three times and write them once (64 B), frozen rows also read their constant three times (+24 B); per free
-    // control point the accumulators are written twice and read four times (288 B); the knot blocks are written and read once
-    // (T_j), the two factor blocks per knot written once and read by both substitutions: 8 block transfers of ldb^2 doubles per knot
-    // on the tiled path; on the wave path T_j is written and the diagonal factor is read (twice) as a triangle: 5 full blocks + 3 triangles
-    const double blk_doubles = d.nk <= 36 ? 5.0 * d.nk * d.nk + 3.0 * (d.nk * (d.nk + 1) / 2) : 8.0 * d.ldb * d.ldb;
+    // control point the accumulators are written twice and read four times (288 B); the knot blocks: on the tiled path 8 block
+    // transfers of ldb^2 doubles per knot (T_j written and read, two factor blocks written once and read by both substitutions); on the
+    // wave path (round 3) T_j is written and read as a triangle and the knot's factor is ONE triangle, M_j = L_j^-T, written once and
+    // staged four times (forward and backward pass of the two substitutions), plus the reciprocal pivots: 7 triangles + 5 nk
+    const double blk_doubles = d.nk <= 36 ? 7.0 * (d.nk * (d.nk + 1) / 2) + 5.0 * d.nk : 8.0 * d.ldb * d.ldb;
     const double bytes_iter = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6) +
                               8.0 * (double)d.nj * blk_doubles;
     PolishWs pw;
@@ -2303,7 +2055,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             fail_reason = 2;  // Newton matrix not positive definite
             break;
         }
-        flops += (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
+        // logged flops of the factorisation: tiled path Cholesky + coupling solve + rank-k update = 7/3 nk^3 per knot; wave path L D L'
+        // (1/3), the triangular inverse M = L^-T (1/3), the coupling rows (3 multiply-adds per entry) and the rank-nk update on the
+        // columns where X is structurally non-zero (1/2): 7/6 nk^3 + 6 nk^2
+        flops += d.nk <= 36 ? (double)d.nj * ((7.0 / 6.0) * d.nk * (double)d.nk * d.nk + 6.0 * d.nk * (double)d.nk)
+                            : (double)d.nj * (7.0 / 3.0) * d.nk * (double)d.nk * d.nk;
         PROF(4);
         TRC(6, trc_sum(d.nk <= 36 ? w.Lf : w.Td, d.nk <= 36 ? (size_t)d.nj * 2 * d.nk * d.nk : (size_t)d.nj * d.ldb * d.ldb, red));
         // ---- predictor
@@ -2663,8 +2419,8 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
-        lds = std::max(lds, sizeof(double) * ((size_t)2 * QP_STAGE_BUFS * (((nkw * (nkw + 1) / 2 + 7) & ~7) + nkw * (nkw + 1)) + (size_t)(M - 1) * nkw + 64));
-        lds = std::max(lds, sizeof(double) * (size_t)(2 * SYRK_LDS_DOUBLES + 64 + 32) + 16);  // chain areas + assembly progress counters
+        lds = std::max(lds, sizeof(double) * ((size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KL_I + 64));  // solve_staged
+        lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 64 + 32) + 16);  // chain areas + assembly progress counters
         if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
             const size_t lb = (size_t)((nk + 15) & ~15);
             lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
