@@ -25,11 +25,12 @@
 #include <vector>
 
 #include "rbp_dev.h"
-#include "knot_lds.inc"
 
 // The QP is tolerance-judged floating point: allow FMA contraction here (the Makefile disables it globally because
 // corridor.hip must round exactly like the reference's float32 code).
 #pragma clang fp contract(fast)
+
+#include "knot_lds.inc"  // (below the pragma: its multiply-adds must contract)
 
 #ifndef QP_THREADS
 #define QP_THREADS 512
@@ -210,6 +211,7 @@ struct QpWs {
     int *wi_of;                     // [nb*oq] column (wi) of control point (a, j6)
     float* nrm;                     // [sum cnt][3] signed normal of frozen row (group, idx): the six rows of a group share it
     double* polish;                 // PolishWs storage
+    double* prof;                   // QP_PROFILE builds: this mission's diagnostic scalars (chain-side timers), else nullptr
 };
 
 __host__ __device__ inline size_t ws_int_count(int N, int M, int nbmax) {
@@ -266,6 +268,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.wi_of = ip, ip += (size_t)nbmax * d.oq;
     w.nrm = (float*)ip;
     w.polish = p + (ws_int_count(d.N, d.M, nbmax) + 1) / 2 + 2;
+    w.prof = nullptr;
     return w;
 }
 
@@ -802,7 +805,7 @@ __device__ inline AsmArgs asm_args(const RowCtx& c) {
 
 // whole-workgroup assembly of all knot blocks (tiled path; the wave path assembles block by block BEHIND the factorisation
 // chains, see twisted_factor)
-__device__ void assemble_blocks(const RowCtx& c, double* lds) {
+__device__ void assemble_blocks(const RowCtx& c, double* lds, bool lower_only = false) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
@@ -815,7 +818,7 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds) {
         __syncthreads();
     }
     const int per_knot = nb * nb * 9;
-    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) assemble_item(A, in_lds ? lds : nullptr, it / per_knot + 1, it % per_knot);
+    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) assemble_item(A, in_lds ? lds : nullptr, it / per_knot + 1, it % per_knot, lower_only);
     // the wave-register path and the LDS-resident tiled path build their coupling blocks from Ek directly
     if (d.nj > 1 && nk > 36 && 3 * lb * (lb + 2) > c.lds_avail) {
         const size_t noff = (size_t)(d.nj - 1) * lb * lb;
@@ -851,7 +854,11 @@ __device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
 
 // Progress counters of the just-in-time block assembly (LDS ints behind the two chain areas): cnt[i] counts the helper waves that
 // have finished the blocks of chain step i; a chain may load its i-th block when all QP_THREADS/64 - 2 of them have.
-#define ASM_HELPERS (QP_THREADS / 64 - 2)
+// Wave roles of the wave path's factorisation: 0, 1 = the two chains; 2, 3 = their companions (M = L^-T behind the chain, see
+// wave_factor_follow); the 512-thread build has four more waves, which assemble the knot blocks; in the 256-thread build the
+// companions assemble the next step's blocks after each M.
+#define ASM_WAVE0 4                                                        // first assembling wave
+#define ASM_HELPERS (QP_THREADS / 64 > ASM_WAVE0 ? QP_THREADS / 64 - ASM_WAVE0 : 0)   // assembling waves
 __device__ __forceinline__ void wait_blocks(int* cnt, int i) {
     while (__hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ASM_HELPERS) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -895,27 +902,11 @@ __device__ __forceinline__ void coupling_coef(const QpWs& w, int j, int dir, int
     e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
 }
 
-// row r of M_j and 1 / d_j -> QpWs::Lf (16 bytes per lane and store instruction: the store path of a CU is issue bound)
+// the diagonal block of one knot: S = T_j (- U) into registers, factorised (column images in C, 1 / d in I); P / pbase: see kl_ldl
 template <int NK>
-__device__ __forceinline__ void store_knot_factor(const double (&m)[NK], const kl_lds* I, double* Mg, int r, bool act) {
-    if (act) {
-        double* row = Mg + (size_t)r * NK;
-        if ((NK & 1) == 0) {
-#pragma unroll
-            for (int k = 0; k < NK; k += 2) *(kl_d2*)(row + k) = kl_d2{m[k], m[k + 1]};
-        } else {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) row[k] = m[k];
-        }
-        Mg[NK * NK + r] = I[r];
-    }
-}
-
-// the diagonal block of one knot: S = T_j (- U), factorised, M = L^-T in MX and in global memory.  Returns false on a non-positive pivot.
-template <int NK>
-__device__ __forceinline__ bool knot_block(const QpWs& w, int j, bool minus_u, kl_lds* base, int r, bool act, int rr) {
+__device__ __forceinline__ bool knot_ldl(const QpWs& w, int j, bool minus_u, kl_lds* base, int r, bool act, int rr, kl_ldsi* P, int pbase) {
     using A = KlArea<NK>;
-    kl_lds *C = base + A::C, *MX = base + A::MX, *I = base + A::I, *U = base + A::C;
+    kl_lds *C = base + A::C, *I = base + A::I, *U = base + A::C;
     double a[NK];
     const double* Tg = w.Td + (size_t)j * NK * NK;
 #pragma unroll
@@ -925,34 +916,85 @@ __device__ __forceinline__ bool knot_block(const QpWs& w, int j, bool minus_u, k
         for (int k = 0; k < NK; ++k) a[k] -= U[rr * KL_LDU + k];
         kl_sync();
     }
-    const bool ok = kl_ldl<NK>(a, C, I, r, act);
+    return kl_ldl<NK>(a, C, I, r, act, P, pbase);
+}
+
+// M = L^-T of the block just factorised: rows into MX (for the coupling factor) and, with 1 / d, into global memory (for the
+// substitutions).  FOLLOW: run by the chain's companion wave concurrently with knot_ldl of the chain wave (kl_follow_LinvT).
+template <int NK, bool FOLLOW>
+__device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base, int r, bool act, kl_ldsi* P, int pbase, int& seen, kl_ldsi* Mdone,
+                                             int done_value) {
+    using A = KlArea<NK>;
+    kl_lds *C = base + A::C, *MX = base + A::MX, *I = base + A::I;
     double m[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) m[k] = (k == r) ? 1.0 : 0.0;
-    kl_row_times_LinvT<NK>(m, C, I);
+    if (FOLLOW)
+        kl_follow_LinvT<NK>(m, C, I, P, pbase);
+    else
+        kl_row_times_LinvT<NK>(m, C, I);
+    const double dinv = I[act ? r : 0];  // (read before the chain is told to go on: its next block overwrites I)
     kl_store_rows<NK>(m, MX, r, act);
-    store_knot_factor<NK>(m, I, w.Lf + (size_t)j * KF_STRIDE(NK), r, act);
-    return ok;
+    if (FOLLOW) kl_publish(Mdone, done_value);
+    double* Mg = w.Lf + (size_t)j * KF_STRIDE(NK);
+    if (act) {  // row r of M_j and 1 / d_j -> QpWs::Lf (16 bytes per lane and store instruction: the store path of a CU is issue bound)
+        double* row = Mg + (size_t)r * NK;
+        if ((NK & 1) == 0) {
+#pragma unroll
+            for (int k = 0; k < NK; k += 2)
+                if (k + 1 >= r) *(kl_d2*)(row + k) = kl_d2{m[k], m[k + 1]};  // (M_j is upper triangular; the staging does not fetch the rest)
+        } else {
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                if (k >= r) row[k] = m[k];
+        }
+        Mg[NK * NK + r] = dinv;
+    }
 }
 
-// one chain: blocks j0, j0+dir, ... (count of them).  On return the chain's LDS area holds the coupling factor X towards the middle
+#ifdef QP_PROFILE  // chain-side timers of the left chain (100 MHz clock, like the phase timers): SC 25 = MFMA update, 26 = waiting for the
+                   // block assembly, 27 = the knot itself (load, factorisation, waiting for M, coupling rows)
+#define CHAIN_T0 long long ct_ = wall_clock64()
+#define CHAIN_T(slot)                                                          \
+    do {                                                                       \
+        const long long t_ = wall_clock64();                                   \
+        if (w.prof && dir > 0 && r == 0) w.prof[slot] += (double)(t_ - ct_);   \
+        ct_ = t_;                                                              \
+    } while (0)
+#else
+#define CHAIN_T0
+#define CHAIN_T(slot)
+#endif
+// progress words of chain h (LDS ints behind the assembly counters): [2h] = images / pivots published by the chain wave (monotone over
+// the whole factorisation: block i publishes i * (NK + 1) + 1 ...), [2h + 1] = blocks whose M rows the companion wave has put into MX
+#define CHAIN_SYNC(cnt, h) ((kl_ldsi*)((cnt) + 64 + 2 * (h)))
+
+// one chain: blocks j0, j0+dir, ... (count of them).  The chain wave factorises; its companion wave (wave_factor_follow) computes
+// M_j = L_j^-T a column or two behind and stores it.  On return the chain's LDS area holds the coupling factor X towards the middle
 // block (MX) and the reciprocal pivots of its last block (I): wave_factor_mid reads both chains' areas.
 template <int NK>
-__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt) {
+__device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w, int j0, int count, int dir, double* ldsW, int* cnt, int h) {
     using A = KlArea<NK>;
     kl_lds* base = (kl_lds*)ldsW;
     kl_lds *MX = base + A::MX, *I = base + A::I, *U = base + A::C;
+    kl_ldsi *P = CHAIN_SYNC(cnt, h), *Mdone = P + 1;
     const int r = threadIdx.x & 63;
     const bool act = r < NK;
     const int rr = act ? r : 0;
     bool ok = true;
+    int seen = 0;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
+        CHAIN_T0;
         if (i > 0) kl_syrk<NK>(MX, I, U, r, false);
-        if (cnt) wait_blocks(cnt, i);
-        if (!knot_block<NK>(w, j, i > 0, base, r, act, rr)) ok = false;
+        CHAIN_T(25);
+        wait_blocks(cnt, i);
+        CHAIN_T(26);
+        if (!knot_ldl<NK>(w, j, i > 0, base, r, act, rr, P, i * (NK + 1))) ok = false;
+        kl_await(Mdone, i + 1, seen);
         double e0, e1, e2, x[NK];
         coupling_coef(w, j, dir, rr, e0, e1, e2);
         kl_coupling_rows<NK>(x, MX, r, act, e0, e1, e2);
+        CHAIN_T(27);
     }
     return ok;
 }
@@ -968,61 +1010,74 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     int nsy = 0;
     if (mid > 0) kl_syrk<NK>(bl + A::MX, bl + A::I, bl + A::C, r, false), nsy++;
     if (mid + 1 < d.nj) kl_syrk<NK>(br + A::MX, br + A::I, bl + A::C, r, nsy > 0), nsy++;
-    if (cnt) wait_blocks(cnt, cnt_idx);
-    return knot_block<NK>(w, mid, nsy > 0, bl, r, act, rr);
+    wait_blocks(cnt, cnt_idx);
+    int seen = 0;
+    kl_ldsi* scratch = CHAIN_SYNC(cnt, 2);  // (nobody follows the middle block: the wave computes M itself)
+    const bool ok = knot_ldl<NK>(w, mid, nsy > 0, bl, r, act, rr, scratch, 0);
+    knot_inverse<NK, false>(w, mid, bl, r, act, scratch, 0, seen, scratch, 0);
+    return ok;
 }
 
 // whole twisted factorisation; every thread of the workgroup calls it.  flag: LDS int.
-// asmb != nullptr: the knot blocks T_j are ASSEMBLED HERE, by the waves that do not run a chain, in the order the chains consume
-// them (step i: blocks i and nj-1-i; last the middle one), each step announced through an LDS counter (wait_blocks): the
-// assembly -- 8-10 % of an interior-point iteration when it was a phase of its own -- disappears behind the dependent chains.
-// ROLE: 0 = compiled for the two chain waves, 1 = for the assembling waves (2..): two __noinline__ functions, see solve_staged.
+// The knot blocks T_j are ASSEMBLED HERE, by waves that do not run a chain, in the order the chains consume them (step i: blocks i
+// and nj-1-i; last the middle one), each step announced through an LDS counter (wait_blocks): the assembly -- 8-10 % of an
+// interior-point iteration when it was a phase of its own -- disappears behind the dependent chains.
+// ROLE: 0 = compiled for the two chain waves, 2 = for their companions (waves 2, 3), 1 = for the assembling waves (4..) of the
+// 512-thread build: three __noinline__ functions with the same workgroup barriers, see solve_staged.
 template <int NK, int ROLE>
 __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, int* flag, double* lds, const AsmArgs* asmb) {
-    const int wave = ROLE == 0 ? (threadIdx.x >> 6) & 1 : 2, mid = twist_mid(d.nj);
+    const int wave = (ROLE == 0 || ROLE == 2) ? (threadIdx.x >> 6) & 1 : 4, mid = twist_mid(d.nj);  // roles 0 / 2: which chain
     const int nl = mid, nr = d.nj - 1 - mid, SF = nl > nr ? nl : nr;
     constexpr int AREA = KlArea<NK>::SIZE;    // one chain wave's LDS area (knot_lds.inc)
-    int* cnt = (int*)(lds + 2 * AREA);  // [SF + 1]
+    int* cnt = (int*)(lds + 2 * AREA);  // [SF + 1] assembly counters, then (at +64) the chains' progress words
     if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
     bool ok = true;
     // rows >= NK of the X images are never written by a row's own lane: clear them once (they only feed unused tile entries)
     for (int i = threadIdx.x; i < 2 * AREA + 64; i += QP_THREADS) lds[i] = 0.0;
     __syncthreads();
-    int* cw = asmb ? cnt : nullptr;
-    // The chain waves issue one dependent instruction every ~32 cycles; whenever the SIMD's arbiter makes one of them queue
-    // behind the ready instructions of other waves (the helpers, the co-resident workgroup's sweeps) the chain stretches, while
-    // giving it the first slot costs the others next to nothing: raise the priority for the chain (+2.5 % at 2000 missions).
+    // The chain waves issue dependent instructions; whenever the SIMD's arbiter makes one of them queue behind the ready instructions
+    // of other waves (the helpers, the co-resident workgroup's sweeps) the chain stretches, while giving it the first slot costs the
+    // others next to nothing: raise the priority for the chain (+2.5 % at 2000 missions).
     if (ROLE == 0) {
         __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);
-        if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cw);
-        if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + AREA, cw);
+        if (wave == 0 && mid > 0) ok = wave_factor_chain<NK>(d, w, 0, mid, +1, lds, cnt, 0);
+        if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + AREA, cnt, 1);
         if (wave == 1) __builtin_amdgcn_s_setprio(0);
     }
-    if (ROLE == 1 && asmb) {
-        const AsmArgs A = *asmb;
-        const int per_knot = A.nb * A.nb * 9, ht = threadIdx.x - 128, HT = QP_THREADS - 128;
-        const int lane = threadIdx.x & 63;
-        for (int i = 0; i <= SF; ++i) {
-            if (i < SF) {
-                // first half of the helper threads: the left chain's block i; second half: the right chain's block nj-1-i
-                const int half = HT / 2, side = ht >= half, t0 = side ? ht - half : ht;
-                const int blk = side ? d.nj - 1 - i : i;
-                if (side ? i < nr : i < nl)
-                    for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it, true);
-            } else {
-                for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it, true);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const AsmArgs A = *asmb;
+    const int per_knot = A.nb * A.nb * 9, ht = threadIdx.x - 64 * ASM_WAVE0, HT = QP_THREADS - 64 * ASM_WAVE0;
+    auto assemble_step = [&](int i) {
+        if (i < SF) {
+            // first half of the assembling threads: the left chain's block i; second half: the right chain's block nj-1-i
+            const int half = HT / 2, side = ht >= half, t0 = side ? ht - half : ht;
+            const int blk = side ? d.nj - 1 - i : i;
+            if (side ? i < nr : i < nl)
+                for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it, true);
+        } else {
+            for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it, true);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (ROLE == 1) {
+        for (int i = 0; i <= SF; ++i) assemble_step(i);
+    }
+    if (ROLE == 2) {
+        // companion of chain `wave`: M_j behind the chain's factorisation of block j
+        const int count = wave == 0 ? nl : nr, j0 = wave == 0 ? 0 : d.nj - 1, dir = wave == 0 ? +1 : -1;
+        kl_lds* base = (kl_lds*)(lds + wave * AREA);
+        kl_ldsi *P = CHAIN_SYNC(cnt, wave), *Mdone = P + 1;
+        const int r = threadIdx.x & 63;
+        int seen = 0;
+        for (int i = 0; i < count; ++i) knot_inverse<NK, true>(w, j0 + i * dir, base, r, r < NK, P, i * (NK + 1), seen, Mdone, i + 1);
     }
     if (!ok && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
     __threadfence_block();
     __syncthreads();
     if (*flag) return false;
     if (ROLE == 0 && wave == 0) {
-        if (!wave_factor_mid<NK>(d, w, lds, lds + AREA, cw, SF) && threadIdx.x == 0) *flag = 1;
+        if (!wave_factor_mid<NK>(d, w, lds, lds + AREA, cnt, SF) && threadIdx.x == 0) *flag = 1;
         __builtin_amdgcn_s_setprio(0);
     }
     __threadfence_block();
@@ -1130,7 +1185,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
 #pragma unroll
             for (int u = 0; u < QP_STAGE_LOADS; ++u) {
                 const int it = base + u * nt;
-                tmp[u] = it < TOT ? src[it] : 0.0;
+                // M_j is upper triangular: what lies left of the diagonal is not fetched (zeros are staged)
+                tmp[u] = (it < TOT && (it >= NK * NK || it % NK >= it / NK)) ? src[it] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < QP_STAGE_LOADS; ++u) {
@@ -1627,7 +1683,7 @@ __device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, 
             default: return twisted_factor<36, ROLE>(d, w, flag, lA, asmb);
         }
     }
-    if (ROLE == 1) return true;  // (the assembling role only exists on the wave path)
+    if (ROLE != 0) return true;  // (the companion / assembling roles only exist on the wave path)
     return factor_tiled(d, w, flag, lA, lds_avail);
 }
 
@@ -1653,6 +1709,7 @@ struct BlkArgs {
     int nk, nj, ldb, lds_avail;
     double *Td, *To, *Lf;
     double* Ek;
+    double* prof;
 };
 // Arguments of a non-kernel function arrive in VECTOR registers, and the compiler treats them as divergent: every pointer, dimension and
 // address derived from them would live in VGPRs for the whole function -- in the 128-VGPR build that is what spills inside the knot
@@ -1669,7 +1726,7 @@ __device__ __forceinline__ void blk_unpack(const BlkArgs& b, QpDims& d, QpWs& w)
     d = QpDims{};
     w = QpWs{};
     d.nk = uni(b.nk), d.nj = uni(b.nj), d.ldb = uni(b.ldb), d.ld = d.nk + 1;
-    w.Td = uni(b.Td), w.To = uni(b.To), w.Lf = uni(b.Lf), w.Ek = uni(b.Ek);
+    w.Td = uni(b.Td), w.To = uni(b.To), w.Lf = uni(b.Lf), w.Ek = uni(b.Ek), w.prof = uni(b.prof);
 }
 __device__ __forceinline__ AsmArgs uni(const AsmArgs& A) {
     return AsmArgs{uni(A.cpacc), uni(A.pwgt), uni(A.Lk), uni(A.Dk), uni(A.normals), uni(A.Td), uni(A.N), uni(A.M), uni(A.nb), uni(A.first), uni(A.oq), uni(A.ldb)};
@@ -1680,7 +1737,7 @@ __device__ __noinline__ bool factor_entry_chain(BlkArgs b, AsmArgs A, double* ld
     QpWs w;
     blk_unpack(b, d, w);
     const AsmArgs Au = uni(A);
-    return factor_dispatch<0>(d, w, uni(lds), uni(flag), uni(b.lds_avail), d.nk <= 36 ? &Au : nullptr);
+    return factor_dispatch<0>(d, w, uni(lds), uni(flag), uni(b.lds_avail), &Au);
 }
 __device__ __noinline__ bool factor_entry_assemble(BlkArgs b, AsmArgs A, double* lds, int* flag) {
     QpDims d;
@@ -1689,8 +1746,17 @@ __device__ __noinline__ bool factor_entry_assemble(BlkArgs b, AsmArgs A, double*
     const AsmArgs Au = uni(A);
     return factor_dispatch<1>(d, w, uni(lds), uni(flag), uni(b.lds_avail), &Au);
 }
+__device__ __noinline__ bool factor_entry_follow(BlkArgs b, AsmArgs A, double* lds, int* flag) {
+    QpDims d;
+    QpWs w;
+    blk_unpack(b, d, w);
+    const AsmArgs Au = uni(A);
+    return factor_dispatch<2>(d, w, uni(lds), uni(flag), uni(b.lds_avail), &Au);
+}
 __device__ __forceinline__ bool factor_entry(const BlkArgs& b, const AsmArgs& A, double* lds, int* flag) {
-    if (b.nk <= 36 && (threadIdx.x >> 6) >= 2) return factor_entry_assemble(b, A, lds, flag);
+    const int wave = threadIdx.x >> 6;
+    if (b.nk <= 36 && wave >= 4) return factor_entry_assemble(b, A, lds, flag);
+    if (b.nk <= 36 && wave >= 2) return factor_entry_follow(b, A, lds, flag);
     return factor_entry_chain(b, A, lds, flag);
 }
 __device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* lds) {
@@ -1792,7 +1858,11 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     int* flag = (int*)(lds_raw + 16);
     double* lds = lds_raw + 32;
     double* lA = lds;
-    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek};
+#ifdef QP_PROFILE
+    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, scal};
+#else
+    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, nullptr};
+#endif
     double* red2 = red;
     int* flag2 = flag;
 
@@ -2046,7 +2116,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             }
         }
         // ---- Newton matrix and factorisation
-        if (d.nk > 36) assemble_blocks(c, lds);  // wave path: assembled behind the factorisation chains (twisted_factor)
+        // wave path, 512 threads: assembled behind the factorisation chains by waves 4.. (twisted_factor); the 256-thread build has no
+        // waves to spare (two chains, two companions) and assembles up front with all of them
+        if (d.nk > 36 || ASM_HELPERS == 0) assemble_blocks(c, lds, d.nk <= 36);
         PROF(3);
         __threadfence_block();
         __syncthreads();

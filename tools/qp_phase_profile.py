@@ -20,5 +20,6 @@ for i, n in enumerate(names):
 print("total", tot.mean() / 1e8 * 1e3, "ms per mission")
 for i, n in enumerate(["polish: candidates+K0+gradient", "polish: V columns + S", "polish: dual active-set (wave 0)", "polish: primal step/verify"]):
     print(f"  {n:34s} {sc[:, 20 + i].mean() / 1e8 * 1e3:9.2f} ms")
+print(f"  left chain: MFMA update {sc[:, 25].mean() / 1e5:.2f} ms, waiting for block assembly {sc[:, 26].mean() / 1e5:.2f} ms, knot work {sc[:, 27].mean() / 1e5:.2f} ms")
 if os.environ.get("LHSTATS"):
     print(f"  LH calls {sc[:, 27].mean():.1f}  appends {sc[:, 25].mean():.1f}  gradient passes {sc[:, 24].mean():.1f} (slot shared with the byte counter: subtract it)  inner solves {sc[:, 26].mean():.1f} per mission")
