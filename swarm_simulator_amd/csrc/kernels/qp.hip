@@ -768,11 +768,8 @@ struct AsmArgs {
 // lower_only (wave path): lane r of a factor chain loads T[k][r] for every k but only ever uses k <= r (T is symmetric, ldl_rows works
 // on the lower triangle), so the other half is neither computed nor written: half of the assembly work and of T's write traffic.  (The
 // chain still LOADS whole rows: predicating its 36 loads and stores costs the dependent chain more than the bytes are worth, measured.)
-__device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ssum, int j, int r, bool lower_only = false) {
-    const int nb = A.nb, oq = A.oq, lb = A.ldb;
-    const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
-    if (lower_only && (a > b || (a == b && k > l))) return;
-    double Sv[6];
+__device__ __forceinline__ void assemble_load(const AsmArgs& A, const double* Ssum, int j, int a, int b, int k, int l, double (&Sv)[6]) {
+    const int nb = A.nb, oq = A.oq;
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
         const int j6 = 6 * (j - 1) + 3 + p;
@@ -786,6 +783,9 @@ __device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ss
         }
         Sv[p] = sv;
     }
+}
+__device__ __forceinline__ void assemble_store(const AsmArgs& A, int j, int a, int b, int k, int l, const double (&Sv)[6], bool lower_only) {
+    const int lb = A.ldb;
     const double* L = A.Lk + 9 * j;
     double* out = A.Td + (size_t)(j - 1) * lb * lb + (size_t)(a * 9 + k * 3) * lb + b * 9 + l * 3;
 #pragma unroll
@@ -798,6 +798,41 @@ __device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ss
             if (!(lower_only && a == b && k == l && e > f)) out[(size_t)e * lb + f] = acc;
         }
 }
+__device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ssum, int j, int r, bool lower_only = false) {
+    const int nb = A.nb;
+    const int a = r / (nb * 9), b = (r / 9) % nb, k = (r / 3) % 3, l = r % 3;
+    if (lower_only && (a > b || (a == b && k > l))) return;
+    double Sv[6];
+    assemble_load(A, Ssum, j, a, b, k, l, Sv);
+    assemble_store(A, j, a, b, k, l, Sv, lower_only);
+}
+
+// All knot blocks' needed halves at once (the 256-thread build, before the factorisation): the 3x3 tiles (A, B) = (3a + k, 3b + l) with
+// A <= B are enumerated directly (no idle threads), and ASM_ILP tiles per thread are in flight at a time -- a tile is six dependent-free
+// loads, a few dozen flops and up to nine stores, so one tile at a time is a chain of memory round trips.
+#define ASM_ILP 3
+__device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
+    const int n3 = 3 * A.nb, per = n3 * (n3 + 1) / 2, total = nj * per;
+    for (int base = threadIdx.x; base < total; base += ASM_ILP * QP_THREADS) {
+        double Sv[ASM_ILP][6];
+        int jj[ASM_ILP], ta[ASM_ILP], tb[ASM_ILP];
+#pragma unroll
+        for (int u = 0; u < ASM_ILP; ++u) {
+            const int it = base + u * QP_THREADS, itc = it < total ? it : total - 1;
+            const int j = itc / per, t = itc - j * per;
+            // row Ai of the upper-triangular enumeration: start(Ai) = Ai * n3 - Ai (Ai - 1) / 2 <= t
+            int Ai = (int)(((2 * n3 + 1) - sqrtf((float)((2 * n3 + 1) * (2 * n3 + 1) - 8 * t))) * 0.5f);
+            if (Ai * n3 - Ai * (Ai - 1) / 2 > t) Ai--;
+            if ((Ai + 1) * n3 - (Ai + 1) * Ai / 2 <= t) Ai++;
+            const int Bi = Ai + t - (Ai * n3 - Ai * (Ai - 1) / 2);
+            jj[u] = j + 1, ta[u] = Ai, tb[u] = Bi;
+            assemble_load(A, nullptr, j + 1, Ai / 3, Bi / 3, Ai % 3, Bi % 3, Sv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < ASM_ILP; ++u)
+            if (base + u * QP_THREADS < total) assemble_store(A, jj[u], ta[u] / 3, tb[u] / 3, ta[u] % 3, tb[u] % 3, Sv[u], true);
+    }
+}
 
 __device__ inline AsmArgs asm_args(const RowCtx& c) {
     return AsmArgs{c.w.cpacc, c.w.pwgt, c.w.Lk, c.w.Dk, c.normals, c.w.Td, c.d.N, c.d.M, c.d.nb, c.d.first, c.d.oq, c.d.ldb};
@@ -805,7 +840,7 @@ __device__ inline AsmArgs asm_args(const RowCtx& c) {
 
 // whole-workgroup assembly of all knot blocks (tiled path; the wave path assembles block by block BEHIND the factorisation
 // chains, see twisted_factor)
-__device__ void assemble_blocks(const RowCtx& c, double* lds, bool lower_only = false) {
+__device__ void assemble_blocks(const RowCtx& c, double* lds) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int nk = d.nk, oq = d.oq, nb = d.nb, lb = d.ldb;
@@ -818,7 +853,7 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds, bool lower_only = 
         __syncthreads();
     }
     const int per_knot = nb * nb * 9;
-    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) assemble_item(A, in_lds ? lds : nullptr, it / per_knot + 1, it % per_knot, lower_only);
+    for (int it = threadIdx.x; it < d.nj * per_knot; it += QP_THREADS) assemble_item(A, in_lds ? lds : nullptr, it / per_knot + 1, it % per_knot);
     // the wave-register path and the LDS-resident tiled path build their coupling blocks from Ek directly
     if (d.nj > 1 && nk > 36 && 3 * lb * (lb + 2) > c.lds_avail) {
         const size_t noff = (size_t)(d.nj - 1) * lb * lb;
@@ -1177,33 +1212,51 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     // block indices handled at step s by the left / right wave (-1: idle)
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
     auto right_j = [&](int s) { return s < SF ? (s - (SF - nr) >= 0 ? nj - 1 - (s - (SF - nr)) : -1) : (s == SF ? -1 : (mid + 1 + (s - SF - 1) <= nj - 1 ? mid + 1 + (s - SF - 1) : -1)); };
-    auto copy_knot = [&](int j, double* dst, int t0, int nt) {  // M_j rows -> rows of KL_LD, then 1 / d_j; QP_STAGE_LOADS loads in flight per lane
-        const double* src = w.Lf + (size_t)j * KF_STRIDE(NK);
-        constexpr int TOT = NK * NK + NK;
-        for (int base = t0; base < TOT; base += QP_STAGE_LOADS * nt) {
-            double tmp[QP_STAGE_LOADS];
+    // Staging (waves 2..): only the upper triangle of M_j and 1 / d_j are fetched -- NE elements per chain -- and every staging thread's
+    // elements (the same for every step) are mapped once per call, so that a step is ONE batch of loads in flight per thread and a
+    // batch of LDS stores.  What lies left of the diagonal in the stage buffers is zero-filled once per call.
+    constexpr int NTRI = NK * (NK + 1) / 2, NE = NTRI + NK, NST = QP_THREADS - 128, MAXE = (2 * NE + NST - 1) / NST;
+    int soff[MAXE], doff[MAXE];  // element u of this thread: source offset inside a knot's Lf slot, destination inside a stage (-1: none)
+    if (ROLE == 1) {
 #pragma unroll
-            for (int u = 0; u < QP_STAGE_LOADS; ++u) {
-                const int it = base + u * nt;
-                // M_j is upper triangular: what lies left of the diagonal is not fetched (zeros are staged)
-                tmp[u] = (it < TOT && (it >= NK * NK || it % NK >= it / NK)) ? src[it] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < QP_STAGE_LOADS; ++u) {
-                const int it = base + u * nt;
-                if (it < NK * NK)
-                    dst[(it / NK) * KL_LD + it % NK] = tmp[u];
-                else if (it < TOT)
-                    dst[SM + it - NK * NK] = tmp[u];
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = (tid - 128) + u * NST;
+            soff[u] = 0, doff[u] = -1;
+            if (e < 2 * NE) {
+                const int side = e >= NE, idx = side ? e - NE : e;
+                if (idx < NTRI) {
+                    int rw = (int)(((2 * NK + 1) - sqrtf((float)((2 * NK + 1) * (2 * NK + 1) - 8 * idx))) * 0.5f);
+                    if (rw * NK - rw * (rw - 1) / 2 > idx) rw--;
+                    if ((rw + 1) * NK - (rw + 1) * rw / 2 <= idx) rw++;
+                    const int k = rw + idx - (rw * NK - rw * (rw - 1) / 2);
+                    soff[u] = rw * NK + k, doff[u] = side * SCH + rw * KL_LD + k;
+                } else {
+                    soff[u] = NK * NK + (idx - NTRI), doff[u] = side * SCH + SM + (idx - NTRI);
+                }
             }
         }
-    };
-    auto stage = [&](int s, double* buf, int t0, int nt) {
+    }
+    for (int i = tid; i < QP_STAGE_BUFS * STG; i += QP_THREADS) lds[i] = 0.0;
+    __syncthreads();
+    auto stage = [&](int s, double* buf) {
         const int jl = left_j(s), jr = right_j(s);
-        if (jl >= 0) copy_knot(jl, buf, t0, nt);
-        if (jr >= 0) copy_knot(jr, buf + SCH, t0, nt);
+        const double* srcl = w.Lf + (size_t)(jl >= 0 ? jl : 0) * KF_STRIDE(NK);
+        const double* srcr = w.Lf + (size_t)(jr >= 0 ? jr : 0) * KF_STRIDE(NK);
+        double tmp[MAXE];
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const bool right = doff[u] >= SCH;
+            const bool on = doff[u] >= 0 && (right ? jr >= 0 : jl >= 0);
+            tmp[u] = on ? (right ? srcr : srcl)[soff[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const bool right = doff[u] >= SCH;
+            if (doff[u] >= 0 && (right ? jr >= 0 : jl >= 0)) buf[doff[u]] = tmp[u];
+        }
     };
-    for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG, tid, QP_THREADS);
+    if (ROLE == 1)
+        for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG);
     __syncthreads();
     const int wave = ROLE == 0 ? (tid >> 6) & 1 : 2, r = tid & 63;  // (role 1 only needs "wave >= 2")
     const bool act = r < NK;
@@ -1214,7 +1267,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         double* buf = lds + (s % QP_STAGE_BUFS) * STG;
         if (ROLE == 1) {
             const int sp = s + QP_STAGE_BUFS - 1;
-            if (sp < nsteps) stage(sp, lds + (sp % QP_STAGE_BUFS) * STG, tid - 128, QP_THREADS - 128);
+            if (sp < nsteps) stage(sp, lds + (sp % QP_STAGE_BUFS) * STG);
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours' v, then backward; x_mid goes to both chains' V
                 const kl_lds* Mst = (const kl_lds*)buf;
@@ -2118,7 +2171,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         // ---- Newton matrix and factorisation
         // wave path, 512 threads: assembled behind the factorisation chains by waves 4.. (twisted_factor); the 256-thread build has no
         // waves to spare (two chains, two companions) and assembles up front with all of them
-        if (d.nk > 36 || ASM_HELPERS == 0) assemble_blocks(c, lds, d.nk <= 36);
+        if (d.nk > 36)
+            assemble_blocks(c, lds);
+        else if (ASM_HELPERS == 0)
+            assemble_needed_halves(asm_args(c), d.nj);
         PROF(3);
         __threadfence_block();
         __syncthreads();
