@@ -810,7 +810,9 @@ __device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ss
 // All knot blocks' needed halves at once (the 256-thread build, before the factorisation): the 3x3 tiles (A, B) = (3a + k, 3b + l) with
 // A <= B are enumerated directly (no idle threads), and ASM_ILP tiles per thread are in flight at a time -- a tile is six dependent-free
 // loads, a few dozen flops and up to nine stores, so one tile at a time is a chain of memory round trips.
+#ifndef ASM_ILP
 #define ASM_ILP 3
+#endif
 __device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
     const int n3 = 3 * A.nb, per = n3 * (n3 + 1) / 2, total = nj * per;
     for (int base = threadIdx.x; base < total; base += ASM_ILP * QP_THREADS) {
@@ -968,6 +970,7 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
         kl_follow_LinvT<NK>(m, C, I, P, pbase);
     else
         kl_row_times_LinvT<NK>(m, C, I);
+    if (FOLLOW) kl_await_opaque(P, pbase + NK + 1);  // the LAST reciprocal pivot is written after the last image was announced
     const double dinv = I[act ? r : 0];  // (read before the chain is told to go on: its next block overwrites I)
     kl_store_rows<NK>(m, MX, r, act);
     if (FOLLOW) kl_publish(Mdone, done_value);

@@ -1,0 +1,24 @@
+"""Developer tool (GPU): copies of the same missions inside one session must agree bit for bit in the control points.
+usage: K=300 REPS=2 [RBP_QP_VARIANT=w2|w4] python tools/determinism_ctrl.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from swarm_simulator_amd import planner
+from swarm_simulator_amd.types import Param
+K = int(os.environ.get("K", "300")); REPS = int(os.environ.get("REPS", "2"))
+p = Param.test_sweep(batch_iter=int(os.environ.get("BITER", "-1")))
+m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), 64, p)
+s = planner.Session(worlds, [m] * K, p, plans)
+first = None
+for rep in range(REPS):
+    s.reset(); s.run(); st = s.download()
+    ctrl = [pl.ctrl.copy() for pl in s.plans]
+    bad = [k for k in range(50, K) if not np.array_equal(ctrl[k].view(np.uint64), ctrl[k % 50].view(np.uint64))]
+    worst = max([float(np.abs(ctrl[k] - ctrl[k % 50]).max()) for k in bad], default=0.0)
+    msg = f"rep {rep}: copies that differ from their first copy: {len(bad)} of {K - 50}, worst |diff| {worst:.3g}, first {bad[:8]}"
+    if first is not None:
+        msg += f"; missions differing from rep 0: {sum(not np.array_equal(a, b) for a, b in zip(ctrl, first))}"
+    else:
+        first = ctrl
+    print(msg, "failed:", int(np.count_nonzero(st)))
