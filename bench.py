@@ -190,6 +190,29 @@ def single_mission_latency(mission, param, world, plan, reps=3):
             "note": "one mission (map1) alone on the GPU, host buffers in and out (H2D/D2H included), min of %d" % reps}
 
 
+def single_sweep_rate(mission_file_agents, param, steps=3):
+    """the reference's real call shape at scale: ONE pass of the 50-map sweep (swarm_traj_planner_rbp_test_all.cpp:49-51) resident, i.e.
+    50 workgroups on 256 CUs.  Returns agent-trajectories/s and ms per sweep (device-resident inputs, like the headline)."""
+    import torch
+    from swarm_simulator_amd import planner
+    from swarm_simulator_amd import _abi as A
+    m, worlds, plans = build_inputs(shard_missions(50, 0, 1), mission_file_agents, param)
+    sess = planner.Session(worlds, [m] * 50, param, plans)
+    stream = torch.cuda.current_stream().cuda_stream
+    sess.reset(stream), sess.run(A.RBP_STAGE_ALL, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sess.reset(stream)
+        sess.run(A.RBP_STAGE_ALL, stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ok = not any(sess.download(stream))
+    sess.close()
+    return {"value": 50 * m.qn / dt if ok else None, "unit": "agent-trajectories/s", "ms_per_sweep": 1e3 * dt,
+            "note": "50 missions resident (map1..50, one workgroup each): one pass of the reference's own sweep"}
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` outside a torchrun environment: run the same command line with N ranks, one per GPU."""
     import socket
@@ -371,6 +394,10 @@ def main():
                 out["latency_ms_single_mission"] = single_mission_latency(mission, param, worlds[0], plans[0])
             except Exception as e:
                 out["latency_ms_single_mission"] = {"error": str(e)}
+            try:
+                out["single_sweep"] = single_sweep_rate(args.agents, param)
+            except Exception as e:
+                out["single_sweep"] = {"error": str(e)}
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.agents, pkw)

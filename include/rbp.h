@@ -167,6 +167,24 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
 int rbp_session_reset(rbp_session* s, void* stream);
 void rbp_session_destroy(rbp_session* s);
 
+/* Device views of one mission's corridor arrays inside a session (HIP device pointers into the session's arena, valid until
+ * rbp_session_destroy): what an agent-sharded Corridor::update exchanges between GPUs WITHOUT a host round trip --
+ * the shard written by a CORRIDOR run restricted with rbp_session_set_agent_range is gathered from / into these arrays on the
+ * device (swarm_simulator_amd/sharded.py: torch tensors over the pointers, one all_gather_into_tensor over RCCL), and the PLANNER stage
+ * of the same session then runs on the completed corridor.  Layouts are those of rbp_plan with the session's strides:
+ * sfc_box [N][max_boxes][6] f64, sfc_time [N][max_boxes] f64, sfc_count [N] i32, rsfc_normal [npair][M][3] f32, rsfc_time [M] f64. */
+typedef struct rbp_device_arrays {
+    void* sfc_count;
+    void* sfc_box;
+    void* sfc_time;
+    void* rsfc_normal;
+    void* rsfc_time;
+    void* status;                   /* [1] i32: the mission's first error so far (0 = ok), written by the kernels */
+    int32_t N, M, max_boxes, npair; /* M, max_boxes: the strides of the arrays (the session's maxima) */
+    int32_t device;
+} rbp_device_arrays;
+int rbp_session_device_arrays(rbp_session* s, int32_t mission, rbp_device_arrays* out);
+
 /* work counters of the last `run`, for the roofline report: see DESIGN.md */
 typedef struct rbp_counters {
     double sfc_samples;     /* getDistance-equivalent samples tested by the SFC kernel (summed over missions) */
@@ -210,7 +228,7 @@ void rbp_release_thread_context(void);
  * against another header must refuse to run (rbp_plan / rbp_counters are written by the library).  rbp_sizeof lets a binding
  * that cannot see this header (ctypes, cgo) compare its own struct sizes with the library's. */
 #define RBP_ABI_VERSION 3  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: this header */
-enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4 };
+enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4, RBP_SIZEOF_DEVICE_ARRAYS = 5 };
 int rbp_abi_version(void);
 size_t rbp_sizeof(int which);
 const char* rbp_version(void);

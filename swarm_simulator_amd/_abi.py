@@ -70,6 +70,12 @@ class rbp_counters(C.Structure):
                 ("qp_row_bytes", C.c_double), ("kkt_max", C.c_double)]
 
 
+class rbp_device_arrays(C.Structure):
+    _fields_ = [("sfc_count", C.c_void_p), ("sfc_box", C.c_void_p), ("sfc_time", C.c_void_p), ("rsfc_normal", C.c_void_p),
+                ("rsfc_time", C.c_void_p), ("status", C.c_void_p), ("N", C.c_int32), ("M", C.c_int32), ("max_boxes", C.c_int32), ("npair", C.c_int32),
+                ("device", C.c_int32)]
+
+
 class rbp_mission_buf(C.Structure):
     _fields_ = [("N", C.c_int32), ("start", c_double_p), ("goal", c_double_p), ("radius", c_double_p),
                 ("speed", c_double_p), ("max_vel", c_double_p), ("max_acc", c_double_p)]

@@ -93,6 +93,7 @@ size_t rbp_sizeof(int which) {
         case RBP_SIZEOF_PARAM: return sizeof(rbp_param);
         case RBP_SIZEOF_PLAN: return sizeof(rbp_plan);
         case RBP_SIZEOF_COUNTERS: return sizeof(rbp_counters);
+        case RBP_SIZEOF_DEVICE_ARRAYS: return sizeof(rbp_device_arrays);
         default: return 0;
     }
 }
@@ -477,6 +478,21 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
 #undef DN
     if (first) g_err = "mission failed with status " + std::to_string(first);
     return first;
+}
+
+int rbp_session_device_arrays(rbp_session* s, int32_t mission, rbp_device_arrays* out) {
+    if (!s || !out) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    const DevSession& d = s->d;
+    if (mission < 0 || mission >= d.K) return fail(RBP_ERR_BAD_ARGUMENT, "mission index outside the session");
+    const size_t k = (size_t)mission;
+    out->sfc_count = d.sfc_count + k * d.N;
+    out->sfc_box = d.sfc_box + k * d.N * d.max_boxes * 6;
+    out->sfc_time = d.sfc_time + k * d.N * d.max_boxes;
+    out->rsfc_normal = d.rsfc_normal + k * d.npair * d.M * 3;
+    out->rsfc_time = d.rsfc_time + k * d.M;
+    out->status = d.status + k;
+    out->N = d.N, out->M = d.M, out->max_boxes = d.max_boxes, out->npair = d.npair, out->device = s->device;
+    return RBP_OK;
 }
 
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {

@@ -379,7 +379,9 @@ __global__ __launch_bounds__(64 * SFC_WAVES, 3) void sfc_kernel(DevSession s) {
     const long long t_start = wall_clock64();
 #endif
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
-    const int mission = blockIdx.x / groups, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform by construction; as a plain threadIdx expression the compiler must treat it (and the agent index, every
+    // pointer and the whole box state derived from it) as divergent, i.e. keep them in vector registers
+    const int mission = blockIdx.x / groups, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
     const int M = s.Mk[mission], P = M + 1, PS = s.M + 1, MB = s.max_boxes, MBcap = s.MBk[mission];  // PS, MB: slot strides
     // LDS: [occupancy mask: s.sfc_mask_words words][per wave: key lists x | y | z, three slab lists][per wave: box_log [MB][P]]

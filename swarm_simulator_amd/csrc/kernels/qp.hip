@@ -811,7 +811,7 @@ __device__ __forceinline__ void assemble_item(const AsmArgs& A, const double* Ss
 // A <= B are enumerated directly (no idle threads), and ASM_ILP tiles per thread are in flight at a time -- a tile is six dependent-free
 // loads, a few dozen flops and up to nine stores, so one tile at a time is a chain of memory round trips.
 #ifndef ASM_ILP
-#define ASM_ILP 3
+#define ASM_ILP 6  // (A/B on one box: 6 is 0.3 % ahead of 3)
 #endif
 __device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
     const int n3 = 3 * A.nb, per = n3 * (n3 + 1) / 2, total = nj * per;

@@ -39,6 +39,20 @@ def lib():
         path = os.environ.get("RBP_HIP_LIB") or os.path.join(A.LIB_DIR, "librbp_hip.so")  # env override: developer A/B builds
         if not os.path.exists(path):
             raise RbpLibraryMissing(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and must find THEM when it initialises
+        # (if this library's /opt/rocm runtime is in the process first, torch.cuda reports "No HIP GPUs are available"); with torch's
+        # copies loaded first, both sides share one runtime whatever the import order -- which streams, events and device pointers
+        # exchanged between them (bench.py, sharded.py) rely on.
+        try:
+            import importlib.util
+            sp = importlib.util.find_spec("torch")
+            if sp is not None and sp.submodule_search_locations:
+                tl = os.path.join(list(sp.submodule_search_locations)[0], "lib")
+                for n in ("libhsa-runtime64.so", "libamdhip64.so"):
+                    if os.path.exists(os.path.join(tl, n)):
+                        C.CDLL(os.path.join(tl, n), mode=C.RTLD_GLOBAL)
+        except Exception:
+            pass
         L = C.CDLL(path)
         P = C.POINTER
         L.rbp_version.restype = C.c_char_p
@@ -51,7 +65,8 @@ def lib():
             L.rbp_sizeof.argtypes = [C.c_int]
             if L.rbp_abi_version() != A.RBP_ABI_VERSION:
                 raise RbpLibraryMissing(f"{path}: ABI version {L.rbp_abi_version()}, this binding expects {A.RBP_ABI_VERSION} (rebuild the library)")
-            for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters)):
+            L.rbp_session_device_arrays.argtypes = [C.c_void_p, C.c_int32, P(A.rbp_device_arrays)]
+            for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters, A.rbp_device_arrays)):
                 if L.rbp_sizeof(which) != C.sizeof(t):
                     raise RbpLibraryMissing(f"{path}: sizeof({t.__name__}) is {L.rbp_sizeof(which)} in the library, {C.sizeof(t)} in this binding")
             L.rbp_release_thread_context.restype = None
@@ -94,6 +109,7 @@ EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
     "rbp_session_run", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
+    "rbp_session_device_arrays",
     "rbp_version", "rbp_abi_version", "rbp_sizeof", "rbp_release_thread_context",
     "rbp_last_error", "rbp_device_count",
     "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
@@ -228,6 +244,27 @@ class Session:
         if rc:
             raise RuntimeError(f"rbp_session_counters rc={rc}: {last_error()}")
         return {k: getattr(ct, k) for k, _ in ct._fields_}
+
+    def device_arrays(self, mission=0):
+        """torch tensors over mission `mission`'s corridor arrays in the session's HBM arena (no copy): dict with sfc_count [N] i32,
+        sfc_box [N][MB][6] f64, sfc_time [N][MB] f64, rsfc_normal [npair][M][3] f32, rsfc_time [M] f64 (MB, M: session strides)."""
+        import torch
+        da = A.rbp_device_arrays()
+        rc = lib().rbp_session_device_arrays(self._h, mission, C.byref(da))
+        if rc:
+            raise RuntimeError(f"rbp_session_device_arrays rc={rc}: {last_error()}")
+
+        class _View:  # __cuda_array_interface__ holder (torch on ROCm reads it like on CUDA)
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        dev = torch.device("cuda", da.device)
+        def view(ptr, shape, typestr):
+            return torch.as_tensor(_View(ptr, shape, typestr), device=dev)
+        N, M, MB, npair = da.N, da.M, da.max_boxes, da.npair
+        return {"sfc_count": view(da.sfc_count, (N,), "<i4"), "sfc_box": view(da.sfc_box, (N, MB, 6), "<f8"),
+                "sfc_time": view(da.sfc_time, (N, MB), "<f8"), "rsfc_normal": view(da.rsfc_normal, (max(npair, 1), M, 3), "<f4")[:npair],
+                "rsfc_time": view(da.rsfc_time, (M,), "<f8"), "status": view(da.status, (1,), "<i4"), "_keepalive": self}
 
     def scalars(self, n=24, stream=None):
         import numpy as np

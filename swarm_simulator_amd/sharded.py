@@ -88,6 +88,79 @@ def gather_corridor(dist, plan: PlanResult, n_agents: int, slices, dev="cpu"):
             unpack_shard(plan, host[r * maxb:r * maxb + lens[r]], slices[r], offs[r])
 
 
+# ---- the same exchange on device buffers (no host round trip between Corridor::update and RBPPlanner::update) -------------------
+def pack_shard_device(arrs, sl, off):
+    """rank-local shard of the session's corridor arrays (torch tensors over HBM, planner.Session.device_arrays) as one byte tensor"""
+    import torch
+    (b, e), (o0, o1) = sl, off
+    parts = [arrs["sfc_count"][b:e], arrs["sfc_box"][b:e], arrs["sfc_time"][b:e], arrs["rsfc_normal"][o0:o1]]
+    return torch.cat([t.contiguous().view(torch.uint8).reshape(-1) for t in parts])
+
+
+def unpack_shard_device(arrs, buf, sl, off):
+    import torch
+    (b, e), (o0, o1) = sl, off
+    pos = 0
+    for name, lo, hi in (("sfc_count", b, e), ("sfc_box", b, e), ("sfc_time", b, e), ("rsfc_normal", o0, o1)):
+        dst = arrs[name][lo:hi]
+        n = dst.numel() * dst.element_size()
+        dst.view(torch.uint8).reshape(-1).copy_(buf[pos:pos + n])
+        pos += n
+    assert pos == buf.numel()
+
+
+def gather_corridor_device(dist, arrs, n_agents, slices):
+    """gather_corridor on the session's own device arrays: pack (device), ONE all_gather_into_tensor (RCCL over xGMI), unpack (device)"""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    M, MB = arrs["rsfc_normal"].shape[1], arrs["sfc_box"].shape[1]
+    _, _, offs, lens = _shard_layout(n_agents, M, MB, slices)
+    maxb = max(max(lens), 1)
+    mine = pack_shard_device(arrs, slices[rank], offs[rank])
+    assert mine.numel() == lens[rank]
+    t = torch.zeros(maxb, dtype=torch.uint8, device=mine.device)
+    t[:mine.numel()] = mine
+    out = torch.empty(world * maxb, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, t)
+    for r in range(world):
+        if r != rank:
+            unpack_shard_device(arrs, out[r * maxb:r * maxb + lens[r]], slices[r], offs[r])
+
+
+def plan_sharded_device(world: World, mission: Mission, param: Param, plan: PlanResult, dist=None, device=None):
+    """plan_sharded with the mission RESIDENT in one session per rank: the CORRIDOR stage runs on the rank's agent slice, the shards are
+    exchanged between the sessions' HBM arrays (gather_corridor_device), the PLANNER stage runs on the completed corridor -- nothing but
+    the 4-byte ok flag crosses to the host between the two stages.  Returns (ok, error text)."""
+    import torch
+    from . import _abi as A
+    dev = torch.device(device if device is not None else "cuda")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    n = mission.qn
+    ws = 1 if dist is None else dist.get_world_size()
+    rank = 0 if dist is None else dist.get_rank()
+    slices = agent_slices(n, ws)
+    stream = torch.cuda.current_stream(idx).cuda_stream
+    sess = planner.Session([world], [mission], param, [plan], device=idx)
+    try:
+        arrs = sess.device_arrays(0)
+        sess.set_agent_range(*slices[rank])
+        sess.run(A.RBP_STAGE_CORRIDOR, stream)
+        flag = (arrs["status"] != 0).to(torch.int32)
+        if dist is not None:
+            dist.all_reduce(flag)  # Corridor::update returns false if any agent / pair failed on any rank
+        if int(flag.item()) != 0:
+            st = sess.download(stream)
+            return False, planner.ERROR_TEXT.get(st[0], "corridor failed on another rank")
+        if dist is not None and ws > 1:
+            gather_corridor_device(dist, arrs, n, slices)
+        sess.set_agent_range(0, n)
+        sess.run(A.RBP_STAGE_PLANNER, stream)
+        st = sess.download(stream)
+        return st[0] == 0, ("" if st[0] == 0 else planner.ERROR_TEXT.get(st[0], str(st[0])))
+    finally:
+        sess.close()
+
+
 class ShardedCorridor:
     """Corridor::update for one mission whose agents are spread over the ranks of `dist` (None = single process)."""
 
@@ -118,7 +191,11 @@ class ShardedCorridor:
 
 def plan_sharded(world: World, mission: Mission, param: Param, plan: PlanResult, dist=None, device="cpu"):
     """Corridor (agent-sharded + all-gather) then RBPPlanner (replicated sweep) for one mission; every rank returns with
-    the complete PlanResult.  Returns (ok, error text)."""
+    the complete PlanResult.  Returns (ok, error text).  On a GPU the mission stays resident in a session and the exchange runs on
+    device buffers (plan_sharded_device); the host-buffer path below serves the CPU (gloo) tests of the exchange logic."""
+    import torch
+    if torch.device(device).type == "cuda":
+        return plan_sharded_device(world, mission, param, plan, dist, device)
     cor = ShardedCorridor(world, mission, param, dist, device)
     if not cor.update(False, plan):
         return False, cor.last_error or "corridor failed on another rank"

@@ -21,3 +21,4 @@ for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for k in sorted(agg): print(f"{k:32s} {agg[k] / n[k]:.4g} per launch ({n[k]} launches)")
 PY
+rm -rf $OUT
