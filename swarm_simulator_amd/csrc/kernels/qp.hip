@@ -196,7 +196,8 @@ struct QpWs {
     double *s, *z, *s2, *z2;        // row state [nslot]: current / next
     double *rh;                     // [nslot] frozen-neighbour rows: the constant of slack = rh - n . x_a
     double *cc, *ds;                // [nslot] polish only: candidate marks / slack at the trial point
-    double *cpacc;                  // [nb*oq][12]: S(6) yv(3) gz(3) per control point, ALL its rows (bounds, pairs, frozen)
+    double *cpacc;                  // [12][nb*oq]: S(6) yv(3) gz(3) per control point, ALL its rows (bounds, pairs, frozen); component-major, so
+                                    // that the passes that read three or six of the twelve (rbase, rhs, assembly) fetch only those
     double *pwgt;                   // [npb*oq] Newton weight of every in-batch pair row (off-diagonal blocks of the knot matrices)
     double *dx, *dxa, *cvec;        // [nb*3*oq]
     double *rbase, *rhs;            // [(M-1)*nk]
@@ -631,12 +632,12 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
             }
         }
         if (accum) {
-            double* acc = w.cpacc + (size_t)it * 12;
+            double* acc = w.cpacc + it;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) acc[e] = S[e];
+            for (int e = 0; e < 6; ++e) acc[(size_t)e * ncp] = S[e];
             if (build) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) acc[6 + e] = yv[e], acc[9 + e] = gz[e];
+                for (int e = 0; e < 3; ++e) acc[(size_t)(6 + e) * ncp] = yv[e], acc[(size_t)(9 + e) * ncp] = gz[e];
             }
         }
     }
@@ -708,7 +709,7 @@ __device__ void rbase_from_acc(const RowCtx& c, double& dmax, double& gmax) {
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) gv += c_Qbase[6 * i + jj] * xs[jj];
             gv *= 2 * w.segsc[m];
-            gv += w.cpacc[((size_t)a * oq + j6) * 12 + 9 + k];  // G'z of ALL rows of this control point (bounds, pairs, frozen)
+            gv += w.cpacc[(size_t)(9 + k) * (d.nb * oq) + (size_t)a * oq + j6];  // G'z of ALL rows of this control point (bounds, pairs, frozen)
             g[q] = -gv;
             gmax = fmax(gmax, fabs(gv));
         }
@@ -734,8 +735,9 @@ __device__ void rhs_from_acc(const RowCtx& c, bool corrector, double sigma_mu) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int j6 = 6 * (j - 1) + 3 + q;
-            const double* ac = w.cpacc + ((size_t)a * oq + j6) * 12;
-            const double gv = corrector ? ac[k] - sigma_mu * ac[3 + k] : ac[6 + k];
+            const double* ac = w.cpacc + (size_t)a * oq + j6;
+            const size_t ncp = (size_t)d.nb * oq;
+            const double gv = corrector ? ac[k * ncp] - sigma_mu * ac[(3 + k) * ncp] : ac[(6 + k) * ncp];
             g[q] = gv;
         }
         const double* L = w.Lk + 9 * j;
@@ -748,6 +750,10 @@ __device__ void rhs_from_acc(const RowCtx& c, bool corrector, double sigma_mu) {
 // ------------------------------------------------------------------------------------------------------------
 // knot blocks:  T_j = blockdiag(D_j) + sum_p S_p (x) t_p t_p',   T_{j+1,j} = blockdiag(E_j')
 // ------------------------------------------------------------------------------------------------------------
+__device__ inline double sym3s(const double* S, size_t stride, int k, int l) {  // the same on a component-major array
+    const int a = k < l ? k : l, b = k < l ? l : k;
+    return S[(size_t)(a == 0 ? b : (a == 1 ? 2 + b : 5)) * stride];
+}
 __device__ inline double sym3(const double* S, int k, int l) {
     const int a = k < l ? k : l, b = k < l ? l : k;
     return S[a == 0 ? b : (a == 1 ? 2 + b : 5)];
@@ -775,7 +781,7 @@ __device__ __forceinline__ void assemble_load(const AsmArgs& A, const double* Ss
         const int j6 = 6 * (j - 1) + 3 + p;
         double sv;
         if (a == b) {
-            sv = Ssum ? sym3(Ssum + ((size_t)a * oq + j6) * 6, k, l) : sym3(A.cpacc + ((size_t)a * oq + j6) * 12, k, l);
+            sv = Ssum ? sym3(Ssum + ((size_t)a * oq + j6) * 6, k, l) : sym3s(A.cpacc + (size_t)a * oq + j6, (size_t)nb * oq, k, l);
         } else {
             const int lo = a < b ? a : b, hi = a < b ? b : a, seg = j6 / 6;
             const float* nv = A.normals + (pair_index(A.N, A.first + lo, A.first + hi) * A.M + seg) * 3;
@@ -851,7 +857,7 @@ __device__ void assemble_blocks(const RowCtx& c, double* lds) {
     // sweep left it in cpacc, parked in LDS when it fits (every entry is read by nine (k, l) work items)
     const bool in_lds = nb * oq * 6 <= c.lds_avail;
     if (in_lds) {
-        for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) lds[it] = w.cpacc[(size_t)(it / 6) * 12 + it % 6];
+        for (int it = threadIdx.x; it < nb * oq * 6; it += QP_THREADS) lds[it] = w.cpacc[(size_t)(it % 6) * (nb * oq) + it / 6];
         __syncthreads();
     }
     const int per_knot = nb * nb * 9;
@@ -946,8 +952,15 @@ __device__ __forceinline__ bool knot_ldl(const QpWs& w, int j, bool minus_u, kl_
     kl_lds *C = base + A::C, *I = base + A::I, *U = base + A::C;
     double a[NK];
     const double* Tg = w.Td + (size_t)j * NK * NK;
+    // T is symmetric: column access = row access; only k <= r was assembled and is used.  Not fetching the unused half (the lanes r < k
+    // re-reading the diagonal entry of row k: -DQP_T_HALF_ROWS) saves 2.6 % of the kernel's HBM-side bytes and COSTS 2.7 % of its time (A/B on
+    // one box, 85.6 k vs 87.9 k agent-trajectories/s): whole rows it is.
 #pragma unroll
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];  // T is symmetric: column access = row access; only k <= r was assembled and is used
+#ifdef QP_T_HALF_ROWS
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + (rr > k ? rr : k)];
+#else
+    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+#endif
     if (minus_u) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] -= U[rr * KL_LDU + k];
@@ -1133,7 +1146,9 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
 // waves 0 / 1 run step s of the left / right chain.  rhs -> z -> x lives in LDS throughout (vec).
 // ROLE: 0 = compiled for the two chain waves, 1 = for the staging waves (2..): two __noinline__ functions (solve_entry_*), so that the
 // staging waves -- a dozen registers -- have no prologue saving callee-saved VGPRs.
+#ifndef KS_CH
 #define KS_CH 12  // k-chunk of the products: loads of the next chunk are issued ahead of the arithmetic of the current one
+#endif
 
 // sum_k Mst[k][rr] * b[k]  (column rr of the staged matrix: consecutive lanes read consecutive addresses)
 template <int NK>
