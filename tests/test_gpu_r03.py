@@ -135,3 +135,28 @@ def test_corridor_only_run_after_a_planner_run_is_not_time_scaled():
     assert np.allclose(g.sfc_time * 1.0, scaled / scaled.max() * g.sfc_time.max(), rtol=1e-12, atol=0)  # same boxes, unscaled
     assert g.sfc_time.max() == T0[-1]
     sess.close()
+
+
+@pytest.mark.parametrize("nag,pkw", [(8, dict(batch_size=1)), (8, dict(batch_size=3)), (6, dict(batch_size=4)), (7, dict(batch_size=2, iteration=2))])
+def test_odd_block_orders_of_the_wave_path_vs_oracle(nag, pkw):
+    """the knot step of kernels/knot_lds.inc is instantiated for nk = 9, 18, 27, 36 (batches of 1..4 agents); the golden cases cover 18
+    and 36 only.  batch_size 1 and 3 give the ODD orders 9 and 27 (other code paths in the pair-wise LDS loads), 6 agents with
+    batch_size 4 a short last batch (36 then 18 inside one mission), 7 agents with batch_size 2 a last batch of one."""
+    p = Param.test_sweep(**pkw)
+    m = host.load_mission("mission_8agents_15.json")
+    if nag < 8:
+        m = m.subset(list(range(nag)))
+    w = host.load_world("map5.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    rc, rep = O.planner_update(m, p, ref)
+    assert rc == 0
+    assert planner.Corridor(w, m, p).update(False, gpu)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu), pl.last_error
+    assert gpu.qp_solves == rep["n_qp"] and gpu.qp_unpolished == 0
+    assert np.abs(ref.ctrl - gpu.ctrl).max() < CTRL_TOL
+    assert abs(ref.total_cost - gpu.total_cost) <= 1e-8 * max(1.0, abs(ref.total_cost))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
