@@ -85,6 +85,9 @@
 #define QP_ROW_UNROLL 2
 #endif
 #endif
+#ifndef QP_ROW_PF
+#define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
+#endif
 #ifndef QP_SIGMA_POW
 #define QP_SIGMA_POW 3  // Mehrotra's centring exponent
 #endif
@@ -415,15 +418,16 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // tracked as io.vmax = max(-ds/s, -dz/z) (the caller takes the reciprocal), which needs no data-dependent division.
 // The corrector term cc = ds_aff dz_aff and the step (ds, dz) are functions of (s, z, ga, gd): the STEP and UPBUILD sweeps
 // recompute them instead of reading them back (three stored arrays fewer, see the note above QpWs).
-template <int PASS>
+// PRE: (s, z) of the row were fetched by the caller (the prefetch ring of the frozen-row stream, QP_ROW_PF)
+template <int PASS, bool PRE = false>
 __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_t r, const QpWs& w, PassIO& io, double cw, double& wgt,
-                                       double& v, double& zo) {
+                                       double& v, double& zo, double s_in = 0.0, double z_in = 0.0) {
     if (PASS == PASS_INIT) {
         const double s = slack < io.s_floor ? io.s_floor : slack;
         w.s[r] = s;
         w.z[r] = io.mu0 / s;
     } else if (PASS == PASS_BUILD) {
-        const double s = w.s[r], z = w.z[r];
+        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
         const double rg = s - slack;
         wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
         v = -wgt * (rg - s);                  // predictor: rc / z = s
@@ -431,7 +435,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         io.sum0 += cw * s * z;
         io.vmax = fmax(io.vmax, fabs(rg));
     } else if (PASS == PASS_AFF) {
-        const double s = w.s[r], z = w.z[r];
+        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
@@ -446,7 +450,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         v = -wgt * (rg - s - cc * iz);
         wgt = wgt * iz;
     } else if (PASS == PASS_STEP) {
-        const double s = w.s[r], z = w.z[r];
+        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
@@ -458,7 +462,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
     } else if (PASS == PASS_UPBUILD) {
         // old state (s, z) at the old point: slack_old = slack + alpha * gd
-        const double s = w.s[r], z = w.z[r];
+        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
         const double rg = s - (slack + io.alpha * gd);
         const double iz = fast_rcp(z);
         const double w0 = z * fast_rcp(s + io.dreg * z);
@@ -480,7 +484,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
     } else if (PASS == PASS_PRESOLVE) {
         io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
     } else if (PASS == PASS_CAND) {
-        const double s = w.s[r], z = w.z[r];
+        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
         wgt = (z > s || s < 1e-6) ? fmax(z / s, 1e-300) : 0.0;  // candidate for the active set; the value orders the warm start
         w.cc[r] = wgt;
         v = slack;
@@ -611,6 +615,56 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
         const int cnt = w.fcnt[grp];
         const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
         const size_t r0 = base + (size_t)d.ncol0 * 64;
+#if QP_ROW_PF > 0
+        // Under load the stream is bound by the memory operations in flight per thread, and unrolling the (heavy) row arithmetic to get
+        // more of them costs registers and instruction cache (unroll 4 measured 8 % slower than 2).  A prefetch ring decouples the two:
+        // the loads of row idx + QP_ROW_PF -- (s, z), the row constant, the group normal: nine registers -- are issued while row idx is
+        // worked on, the arithmetic is not replicated.
+        constexpr bool rd_sz = PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_CAND;
+        double ps[QP_ROW_PF], pz[QP_ROW_PF], ph[QP_ROW_PF];
+        float pn[QP_ROW_PF][3];
+#pragma unroll
+        for (int u = 0; u < QP_ROW_PF; ++u) {
+            const int iu = u < cnt ? u : (cnt > 0 ? cnt - 1 : 0);
+            const size_t ru = r0 + (size_t)iu * 64;
+            ps[u] = (rd_sz && cnt > 0) ? w.s[ru] : 0.0, pz[u] = (rd_sz && cnt > 0) ? w.z[ru] : 0.0, ph[u] = cnt > 0 ? w.rh[ru] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) pn[u][e] = cnt > 0 ? nr[3 * iu + e] : 0.0f;
+        }
+        for (int idx = 0; idx < cnt; ++idx) {
+            const size_t r = r0 + (size_t)idx * 64;
+            const double n0 = pn[0][0], n1 = pn[0][1], n2 = pn[0][2], rhv = ph[0], s_in = ps[0], z_in = pz[0];
+#pragma unroll
+            for (int u = 0; u + 1 < QP_ROW_PF; ++u) {
+                ps[u] = ps[u + 1], pz[u] = pz[u + 1], ph[u] = ph[u + 1];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) pn[u][e] = pn[u + 1][e];
+            }
+            {
+                const int ix = idx + QP_ROW_PF < cnt ? idx + QP_ROW_PF : cnt - 1;  // (past the end: the last row again, never used)
+                const size_t rx = r0 + (size_t)ix * 64;
+                if (rd_sz) ps[QP_ROW_PF - 1] = w.s[rx], pz[QP_ROW_PF - 1] = w.z[rx];
+                ph[QP_ROW_PF - 1] = w.rh[rx];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) pn[QP_ROW_PF - 1][e] = nr[3 * ix + e];
+            }
+            const double slack = rhv - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
+            double wgt = 0, v = 0, zo = 0;
+            row_op<PASS, rd_sz>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, 1.0, wgt, v, zo, s_in, z_in);
+            if (cand && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
+            if (accum) {
+                if (build) {
+                    S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
+                    S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
+                    gz[0] += zo * n0, gz[1] += zo * n1, gz[2] += zo * n2;
+                    yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+                } else {
+                    S[0] += v * n0, S[1] += v * n1, S[2] += v * n2;
+                    S[3] += wgt * n0, S[4] += wgt * n1, S[5] += wgt * n2;
+                }
+            }
+        }
+#else
 #pragma unroll QP_ROW_UNROLL
         for (int idx = 0; idx < cnt; ++idx) {
             const size_t r = r0 + (size_t)idx * 64;
@@ -631,6 +685,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
                 }
             }
         }
+#endif
         if (accum) {
             double* acc = w.cpacc + it;
 #pragma unroll
