@@ -374,7 +374,10 @@ __global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
     }
 }
 
-__global__ __launch_bounds__(64 * SFC_WAVES, 3) void sfc_kernel(DevSession s) {
+#ifndef SFC_WAVES_PER_EU
+#define SFC_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(DevSession s) {
 #ifdef SFC_PROFILE
     const long long t_start = wall_clock64();
 #endif

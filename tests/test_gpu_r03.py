@@ -160,3 +160,24 @@ def test_odd_block_orders_of_the_wave_path_vs_oracle(nag, pkw):
     assert abs(ref.total_cost - gpu.total_cost) <= 1e-8 * max(1.0, abs(ref.total_cost))
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
+def test_joint_qp_32_agents_block_order_288_vs_oracle():
+    """plan/sequential=false (the reference's code default, param.hpp:67): ONE QP over all 32 agents, knot blocks of order nk = 288 on the
+    MFMA-tiled path.  Round 2 compared the joint path with the oracle at 8 and 16 agents (nk 72, 144) only."""
+    p = Param.test_sweep(sequential=False)
+    m = host.load_mission("mission_32agents_15.json")
+    w = host.load_world("map7.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    ref, gpu = init.clone_inputs(), init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    rc, rep = O.planner_update(m, p, ref)
+    assert rc == 0 and rep["n_qp"] == 1 and rep["n_polished"] == 1
+    assert planner.Corridor(w, m, p).update(False, gpu)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, gpu), pl.last_error
+    assert gpu.qp_solves == 1 and (gpu.qp_unpolished == 0 or gpu.kkt_max < 1e-7)
+    assert np.abs(ref.ctrl - gpu.ctrl).max() < CTRL_TOL
+    assert abs(ref.total_cost - gpu.total_cost) <= 1e-8 * max(1.0, abs(ref.total_cost))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
