@@ -49,7 +49,9 @@ def test_c4_256_agents_single_rank():
     assert np.array_equal(ref.sfc_count, gpu.sfc_count) and np.array_equal(ref.sfc_box, gpu.sfc_box)
     assert np.array_equal(ref.rsfc_normal.view(np.uint32), gpu.rsfc_normal.view(np.uint32))
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
-    assert veq < 1e-8 and vbox < 1e-8 and vrs < 1e-8
+    # equality rows 5e-8 (rows of Aeq_base carry factors up to 20 and a control point snapped onto an active face moves by <= 5e-9 m:
+    # DESIGN.md 4, the EQ_TOL of the other parity tests), inequality rows 1e-8
+    assert veq < 5e-8 and vbox < 1e-8 and vrs < 1e-8, (veq, vbox, vrs)
     assert abs(obj - gpu.total_cost) < 1e-6 * max(1.0, obj)
     assert gpu.qp_unpolished == 0 and gpu.qp_solves == 64
     # optimality, not only feasibility: the independent numpy certificate (tests/golden/make_kkt_reference.py) on the first, a middle
