@@ -897,6 +897,89 @@ __device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
     }
 }
 
+// The same through the LDS, one wave per knot (r03): a knot's inputs -- the weight sums of its six control points for every batch agent,
+// the pair weights, the pairs' normals of the two segments -- are fetched with coalesced loads into the wave's LDS scratch, the tiles are
+// computed from there into a symmetric LDS image of the block, and the image leaves as whole rows (16 bytes per lane, 1 KB per store
+// instruction).  Tile by tile from / to global memory a knot costs ~10^4 scattered 8-byte transactions, this way ~10^2 line requests --
+// and under load the memory system is bound by transactions (see the row sweeps).  lds: QP_THREADS / 64 scratch areas of ASML_DOUBLES.
+#define ASML_DOUBLES(nk, nb) ((nk) * KL_LD + (nb) * 36 + 3 * (nb) * ((nb) - 1) + 3 * (nb) * ((nb) - 1) + 8)
+__device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
+    const int nb = A.nb, oq = A.oq, nk = 9 * nb, npb = nb * (nb - 1) / 2, n3 = 3 * nb, per = n3 * (n3 + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = QP_THREADS / 64;
+    const size_t ncp = (size_t)nb * oq;
+    kl_lds* Timg = (kl_lds*)(lds + (size_t)wave * ASML_DOUBLES(nk, nb));
+    kl_lds* Sin = Timg + nk * KL_LD;  // [a][sym][p]
+    kl_lds* Pw = Sin + nb * 36;      // [pair][p]
+    kl_lds* Nr = Pw + 6 * npb;       // [pair][left / right segment][3]
+    // this lane's tiles of a block's upper half (the same for every knot)
+    int tA[2], tB[2], ntile = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = lane + 64 * u, tc = t < per ? t : 0;
+        int ai = (int)(((2 * n3 + 1) - sqrtf((float)((2 * n3 + 1) * (2 * n3 + 1) - 8 * tc))) * 0.5f);
+        if (ai * n3 - ai * (ai - 1) / 2 > tc) ai--;
+        if ((ai + 1) * n3 - (ai + 1) * ai / 2 <= tc) ai++;
+        tA[u] = ai, tB[u] = ai + tc - (ai * n3 - ai * (ai - 1) / 2);
+        if (t < per) ntile = u + 1;
+    }
+    for (int j = wave; j < nj; j += NW) {
+        const int jn = j + 1, j60 = 6 * j + 3;  // first control point of the knot
+        for (int idx = lane; idx < nb * 36; idx += 64) {
+            const int a = idx / 36, e = (idx / 6) % 6, pp = idx % 6;
+            Sin[idx] = A.cpacc[(size_t)e * ncp + (size_t)a * oq + j60 + pp];
+        }
+        for (int idx = lane; idx < 6 * npb; idx += 64) Pw[idx] = A.pwgt[(size_t)(idx / 6) * oq + j60 + idx % 6];
+        for (int idx = lane; idx < 6 * npb; idx += 64) {
+            const int pw = idx / 6, sg = (idx / 3) % 2, c3 = idx % 3;
+            int lo = 0, rest = pw;  // pair pw = (lo, hi) in the order lo * nb - lo (lo + 1) / 2 + (hi - lo - 1)
+            while (rest >= nb - 1 - lo) rest -= nb - 1 - lo, lo++;
+            const int hi = lo + 1 + rest;
+            Nr[idx] = (double)A.normals[(pair_index(A.N, A.first + lo, A.first + hi) * A.M + (j + sg)) * 3 + c3];
+        }
+        double L[9], Dk[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) L[e] = A.Lk[9 * jn + e], Dk[e] = A.Dk[9 * jn + e];
+        kl_sync();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u < ntile) {
+                const int Ai = tA[u], Bi = tB[u], a = Ai / 3, k = Ai % 3, b = Bi / 3, l = Bi % 3;
+                double Sv[6];
+                if (a == b) {
+                    const int kk = k < l ? k : l, ll = k < l ? l : k, sym = kk == 0 ? ll : (kk == 1 ? 2 + ll : 5);
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp) Sv[pp] = Sin[(a * 6 + sym) * 6 + pp];
+                } else {  // a < b
+                    const int pw = a * nb - a * (a + 1) / 2 + (b - a - 1);
+#pragma unroll
+                    for (int pp = 0; pp < 6; ++pp) Sv[pp] = -Pw[pw * 6 + pp] * Nr[(pw * 2 + (pp >= 3)) * 3 + k] * Nr[(pw * 2 + (pp >= 3)) * 3 + l];
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) {
+                        double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
+                        if (e == f) acc += Sv[3 + e];
+                        if (Ai == Bi) acc += Dk[3 * e + f];
+                        Timg[(3 * Ai + e) * KL_LD + 3 * Bi + f] = acc;
+                        Timg[(3 * Bi + f) * KL_LD + 3 * Ai + e] = acc;
+                    }
+            }
+        }
+        kl_sync();
+        double* Tg = A.Td + (size_t)j * nk * nk;
+        if ((nk & 1) == 0) {
+            for (int idx = lane; idx < nk * nk / 2; idx += 64) {
+                const int r = (2 * idx) / nk, k2 = (2 * idx) % nk;
+                *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
+            }
+        } else {
+            for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
+        }
+        kl_sync();
+    }
+}
+
 __device__ inline AsmArgs asm_args(const RowCtx& c) {
     return AsmArgs{c.w.cpacc, c.w.pwgt, c.w.Lk, c.w.Dk, c.normals, c.w.Td, c.d.N, c.d.M, c.d.nb, c.d.first, c.d.oq, c.d.ldb};
 }
@@ -2247,7 +2330,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         if (d.nk > 36)
             assemble_blocks(c, lds);
         else if (ASM_HELPERS == 0)
-            assemble_needed_halves(asm_args(c), d.nj);
+            assemble_blocks_lds(asm_args(c), d.nj, lds);
         PROF(3);
         __threadfence_block();
         __syncthreads();
