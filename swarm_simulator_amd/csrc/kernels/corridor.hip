@@ -37,8 +37,8 @@ struct AxisCache {
 //   v = lo; c = 0; while (v < hi + 1e-6) { coord = (c == 0 && lo > world_min + 1e-6) ? lo - 1e-6 : v + 1e-6; ... v += res }
 // and DynamicEDTOctomap::getDistance's key computation k(v) = floor((1/res_map) * (double)(float)coord) - key_min.
 //
-// The reference's coordinates are the partial sums of a chain of double additions -- sequential, 32 cycles per addition on
-// this machine, and a list of ~100 samples is rebuilt every time the lower end of the box moves.  Instead lane c evaluates
+// The reference's coordinates are the partial sums of a chain of double additions -- sequential, one lane working while 63 wait --
+// and a list of ~100 samples is rebuilt every time the lower end of the box moves.  Instead lane c evaluates
 // the closed form t = lo + c*res, which differs from the c-th partial sum by at most d = (c + 4) * 2^-52 * max|v| (c roundings
 // of at most half an ulp each in the chain, two in the closed form, doubled), and because k(.) and the loop test are
 // MONOTONE in v, k(t - d) == k(t + d) proves that the chain value has that key too (and t + d < lim / t - d >= lim decide

@@ -14,13 +14,14 @@
 //     sweep; step into the ping-pong arrays + neighbourhood test + next iteration's weights);
 //   * per-control-point 3x3 accumulators are expanded into the knot blocks (no atomics) by the six waves that would otherwise
 //     idle behind the factorisation chains, block by block just ahead of them (twisted_factor);
-//   * the block-tridiagonal factorisation: nk <= 36 twisted two-wave chains, L D L' with a unit factor, one block row per lane in
-//     VGPRs and MFMA rank-k updates; wider batches an MFMA-tiled path (LDS-resident for nk <= 72);
+//   * the block-tridiagonal factorisation: nk <= 36 twisted two-wave chains, L D L' with column images broadcast through LDS
+//     (knot_lds.inc), the explicit inverse factor M = L^-T by a companion wave, MFMA rank-k updates; wider batches an MFMA-tiled path
+//     (LDS-resident for nk <= 72); substitutions as matrix-vector products with the staged M;
 //   * an active-set polish (qp_polish.inc) turns the interior-point answer into the exact optimum, verified by a full
 //     KKT check; from the second Gauss-Seidel pass on it is tried before any interior-point iteration.
 // Batches of a mission are solved strictly in the reference's order (Gauss-Seidel, :140-148); parallelism comes
 // from the 3*nb coupled blocks inside a batch and from the K missions of a session.  The file is compiled twice
-// (256 / 128 VGPRs, see the note above planner_workspace_bytes).
+// (512 / 256 threads per workgroup, see the note above planner_workspace_bytes).
 #include <algorithm>
 #include <vector>
 
@@ -46,44 +47,11 @@
 #ifndef QP_MU0
 #define QP_MU0 3e-1     // interior-point start: z = mu0 / s with s = max(slack, s_floor)  (tuned on the 50-map sweep)
 #endif
-#ifndef QP_SOLVE_UNROLL_N  // dependent column loops of the substitutions (0 = completely unrolled).  A/B on one box: the 128-VGPR build gains
-#if QP_WAVES_PER_EU >= 4   // 3.6 % of the planner time with 6, 12 or 18 (the fully unrolled loops let the scheduler hoist LDS loads until it spills
-#define QP_SOLVE_UNROLL_N 12  // on the chain); the 256-VGPR build preloads the factor row into registers and needs the full unroll (208 vs 263 ms)
-#else
-#define QP_SOLVE_UNROLL_N 0
-#endif
-#endif
-#if QP_SOLVE_UNROLL_N == 0
-#define QP_SOLVE_UNROLL _Pragma("unroll")
-#elif QP_SOLVE_UNROLL_N == 6
-#define QP_SOLVE_UNROLL _Pragma("unroll 6")
-#elif QP_SOLVE_UNROLL_N == 12
-#define QP_SOLVE_UNROLL _Pragma("unroll 12")
-#else
-#define QP_SOLVE_UNROLL _Pragma("unroll 18")
-#endif
-#ifndef QP_DOT_UNROLL_N  // coupling-block dot products of the substitutions: groups of four terms unrolled (0 = all nine).  A/B on one box:
-#define QP_DOT_UNROLL_N 3  // 3 gives the single mission -2 % (208 -> 204 ms), throughput unchanged
-#endif
-#if QP_DOT_UNROLL_N == 0
-#define QP_DOT_UNROLL _Pragma("unroll")
-#elif QP_DOT_UNROLL_N == 1
-#define QP_DOT_UNROLL _Pragma("unroll 1")
-#else
-#define QP_DOT_UNROLL _Pragma("unroll 3")
-#endif
 #ifndef QP_UNI_POLISH
 #define QP_UNI_POLISH 1
 #endif
-#ifndef QP_STAGE_LOADS
-#define QP_STAGE_LOADS 8  // staging of a factor block (1296 doubles) by 384 or 512 threads: loads in flight per lane
-#endif
-#ifndef QP_ROW_UNROLL  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box, planner time of the 128-VGPR build:
-#if QP_WAVES_PER_EU >= 4  // 1: 2094, 2: 2116, 3: 2135, 4: 2172, 8: 2165 ms; single mission (256 VGPRs): 2 is best
-#define QP_ROW_UNROLL 1
-#else
-#define QP_ROW_UNROLL 2
-#endif
+#ifndef QP_ROW_UNROLL  // frozen-row stream of a sweep: rows unrolled per thread.  A/B on one box (r03, 2000 missions resident): 1: 82.8 k,
+#define QP_ROW_UNROLL 2  // 2: 86.0 k, 4: 78.8 k agent-trajectories/s
 #endif
 #ifndef QP_ROW_PF
 #define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
@@ -101,13 +69,16 @@
 #define QP_SFLOOR 1e-1
 #endif
 #ifndef QP_WAVES_PER_EU
-#define QP_WAVES_PER_EU (512 / QP_THREADS)  // 2 with 512 threads: all 256 VGPRs for the wave-register path
+#define QP_WAVES_PER_EU 2  // 256 VGPRs per lane in both builds (one 512-thread or two 256-thread workgroups per CU)
 #endif
 #ifndef QP_CHAIN_PRIO
 #define QP_CHAIN_PRIO 3  // s_setprio level of the waves that run a dependent chain (factor, substitutions, dual active-set solve)
 #endif
 #ifndef QP_STAGE_BUFS
-#define QP_STAGE_BUFS (QP_THREADS >= 512 ? 3 : 2)  // (the 256-thread build shares a CU's LDS between two workgroups)
+#ifndef QP_STAGE_BUFS_BIG
+#define QP_STAGE_BUFS_BIG 3
+#endif
+#define QP_STAGE_BUFS (QP_THREADS >= 512 ? QP_STAGE_BUFS_BIG : 2)  // (the 256-thread build shares a CU's LDS between two workgroups)
 #endif
 #ifndef QP_RCP_NEWTON
 #define QP_RCP_NEWTON 2
@@ -698,19 +669,14 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
     }
 }
 
-// A sweep of the interior-point loop.  In the 256-VGPR build it is a stand-alone function (own register allocation,
-// +3 %) that reads the row context from an LDS copy made once per batch QP (passing the 500-byte struct by value would
-// travel through scratch memory); in the 128-VGPR build inlining measured 1.4 % better.
+// A sweep of the interior-point loop: a stand-alone function (own register allocation, +3 %) that reads the row context from an LDS
+// copy made once per batch QP (passing the 500-byte struct by value would travel through scratch memory).
 template <int PASS>
 __device__ __noinline__ PassIO sweep(const RowCtx* cl, PassIO io) {
     row_pass<PASS>(*cl, io);
     return io;
 }
-#if QP_WAVES_PER_EU >= 4
-#define SWEEP(PASS) row_pass<PASS>(c, io)
-#else
 #define SWEEP(PASS) io = sweep<PASS>(&c_lds, io)
-#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // control-space <-> reduced-space maps
@@ -1921,7 +1887,7 @@ struct BlkArgs {
     double* prof;
 };
 // Arguments of a non-kernel function arrive in VECTOR registers, and the compiler treats them as divergent: every pointer, dimension and
-// address derived from them would live in VGPRs for the whole function -- in the 128-VGPR build that is what spills inside the knot
+// address derived from them would live in VGPRs for the whole function -- that is what spills inside the knot
 // loops, and a spill reload on a dependent chain costs a memory round trip.  They are wave-uniform by construction, so they are moved to
 // scalar registers explicitly (v_readfirstlane); everything computed from them then stays scalar.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -2423,9 +2389,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             double* t0 = c.w.s;
             c.w.s = c.w.s2, c.w.s2 = t0;
             t0 = c.w.z, c.w.z = c.w.z2, c.w.z2 = t0;
-#if QP_WAVES_PER_EU < 4
             if (tid == 0) c_lds.w.s = c.w.s, c_lds.w.s2 = c.w.s2, c_lds.w.z = c.w.z, c_lds.w.z2 = c.w.z2;
-#endif
             __syncthreads();
         }
         rows_swept += 2 * nrows_free;
@@ -2666,9 +2630,9 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
 
 }  // namespace
 
-// This file is compiled twice (csrc/Makefile): QP_WAVES_PER_EU=2 (all 256 VGPRs, one workgroup per CU: fastest single
-// mission) and QP_WAVES_PER_EU=4 (128 VGPRs, low-register factor chain, two workgroups per CU: +6 % throughput when there
-// are at least two missions per CU).  QP_SUFFIX names the entry points; abi/session.hip picks one per launch.
+// This file is compiled twice (csrc/Makefile), both with 256 VGPRs per lane: QP_THREADS=512 (one workgroup per CU: the fastest single
+// mission, its sweeps prefetch four rows ahead) and QP_THREADS=256 (two workgroups per CU: the throughput build, used when there are
+// more missions than CUs).  QP_SUFFIX names the entry points; abi/session.hip picks one per launch.
 #ifndef QP_SUFFIX
 #define QP_SUFFIX _w2
 #endif
