@@ -365,7 +365,10 @@ def main():
                                    f"M = makespan + 2 (M in {Ms}, no padding), sequential={str(not args.joint).lower()} "
                                    f"batch_size={args.batch_size} iteration={args.iteration} (plan_rbp_test.launch keys)",
                        "agents": N, "segments": Ms, "missions_per_gpu": K, "parallelism": f"missions sharded over {n_ranks} GPU(s)",
-                       "all_missions_ok": not any(status), "qp_kernel_variant": variant, "baseline_config": args.config or "c3"},
+                       "all_missions_ok": not any(status), "qp_kernel_variant": variant, "baseline_config": args.config or "c3",
+                       "block_order": ("plain (RBP_QP_ORDER=0)" if os.environ.get("RBP_QP_ORDER", "1")[:1] == "0" else
+                                       "longest mission of the session's previous run first (the warm-up steps supply the history; the first "
+                                       "run of a session uses plain order; results do not depend on the order)")},
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},
             "roofline": {"bound": "hbm", "kernel": "qp_batch_kernel", "achieved": qp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": qp_gbs / HBM_PEAK_GBS, "hbm_frac": qp_gbs / HBM_PEAK_GBS,

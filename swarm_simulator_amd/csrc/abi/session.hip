@@ -209,7 +209,8 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
                          al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
                          al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
                          2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
-                         al(sizeof(unsigned long long) * K * CT_N) + al(s->qp_ws_per_mission * K) + 4096;
+                         al(sizeof(unsigned long long) * K * CT_N) + al(sizeof(int) * K) + al(sizeof(unsigned long long) * K) +
+                         al(s->qp_ws_per_mission * K) + 4096;
     if (ctx) {
         if (ctx->busy) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: the context's arena is in use by another session");
         if (ctx->device != device) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: context belongs to another device");
@@ -294,6 +295,12 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     d.status = A.take<int>(K);
     d.scalars = A.take<double>((size_t)K * SC_N);
     d.counters = A.take<unsigned long long>((size_t)K * CT_N);
+    {
+        const char* e = getenv("RBP_QP_ORDER");  // "0": plain block order (diagnostics)
+        const bool on = !(e && e[0] == '0');
+        d.qp_order = on ? A.take<int>(K) : nullptr;
+        d.qp_cost = on ? A.take<unsigned long long>(K) : nullptr;
+    }
     s->qp_ws = A.take<char>(s->qp_ws_per_mission * K);
     if (A.off > A.size) return fail(RBP_ERR_HIP, "arena overflow (internal sizing error)");
     bool have_corr = true;

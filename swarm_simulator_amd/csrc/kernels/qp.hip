@@ -2003,9 +2003,9 @@ __device__ double trc_sum(const double* p, size_t n, double* red) {
 // ------------------------------------------------------------------------------------------------------------
 // one batch QP of one mission (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int batch, int nbmax,
+__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
                                               int reset_cost, int lds_doubles, int pass_index) {
-    const int mission = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (S.status[mission] != 0) return;
     // M of this mission: made wave-uniform explicitly (an SGPR like every other dimension; as a per-lane value it was spilled
     // and reloaded under divergent control flow with some lanes reading garbage)
@@ -2456,12 +2456,36 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
 // and with more missions than CUs the hardware dispatcher balances them.
 __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(DevSession S, double* ws_base, size_t ws_stride, int passes,
                                                                int biter, int nbmax, int lds_doubles) {
+    // longest missions of the previous run first (DevSession::qp_order): with more missions than resident workgroups the step ends when
+    // the last mission does, and a long one started late leaves most of the chip idle behind it
+    const int mission = S.qp_order ? __builtin_amdgcn_readfirstlane(S.qp_order[blockIdx.x]) : (int)blockIdx.x;
+    const long long t_start = wall_clock64();
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
-            qp_batch_body(S, ws_base, ws_stride, l, nbmax, (int)(l == 0), lds_doubles, it);
+            qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it);
             __threadfence_block();
             __syncthreads();
         }
+    if (S.qp_cost && threadIdx.x == 0) S.qp_cost[mission] = (unsigned long long)(wall_clock64() - t_start) + 1;
+}
+
+// rank of every mission by the previous run's cost, longest first (ties by index); identity while any mission has no cost yet
+__global__ __launch_bounds__(256) void qp_order_kernel(DevSession S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S.K) return;
+    const unsigned long long c = S.qp_cost[k];
+    int rank = 0;
+    bool valid = c != 0;
+    for (int o = 0; o < S.K; ++o) {
+        const unsigned long long co = S.qp_cost[o];
+        valid = valid && co != 0;
+        rank += (co > c || (co == c && o < k)) ? 1 : 0;
+    }
+    // (valid is the same for every thread: each of them has looked at all costs)
+    if (valid)
+        S.qp_order[rank] = k;
+    else
+        S.qp_order[k] = k;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2674,6 +2698,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
             lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
         }
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (s.p.iteration > 0 && s.qp_order) hipLaunchKernelGGL(qp_order_kernel, dim3((s.K + 255) / 256), dim3(256), 0, st, s);
         if (s.p.iteration > 0)
             hipLaunchKernelGGL(qp_batch_kernel, dim3(s.K), dim3(QP_THREADS), lds, st, s, (double*)qp_ws,
                                ws_bytes_per_mission / sizeof(double), s.p.iteration, biter, bs, (int)(lds / sizeof(double)) - 2);

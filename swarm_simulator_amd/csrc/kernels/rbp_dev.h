@@ -67,6 +67,11 @@ struct DevSession {
     int* status;              // [K] first error per mission (0 ok)
     double* scalars;          // [K][8]: time_scale, total_cost, ipm_iters, qp_solved, polished, ...
     unsigned long long* counters;  // [K][4]: sfc samples, ...
+    // block -> mission order of the QP kernel (r03): a session that is run again starts its LONGEST missions first (wall-clock cycles
+    // of each mission's workgroup in the previous run, kept across rbp_session_reset); identity on the first run.  Results do not
+    // depend on the order (every mission is a workgroup of its own); nullptr disables it (RBP_QP_ORDER=0).
+    int* qp_order;                 // [K]
+    unsigned long long* qp_cost;   // [K]
 };
 
 enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3, SC_POLISHED = 4, SC_FLOPS = 5, SC_ROWS = 6,

@@ -181,3 +181,31 @@ def test_joint_qp_32_agents_block_order_288_vs_oracle():
     assert abs(ref.total_cost - gpu.total_cost) <= 1e-8 * max(1.0, abs(ref.total_cost))
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, gpu)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
+def test_longest_first_block_order_does_not_change_results(monkeypatch):
+    """a session that is run again starts the missions that took longest in the previous run first (DevSession::qp_order); every mission
+    is a workgroup of its own, so the plans must be bit-identical to the first run's and to a session with the order switched off"""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_8agents_15.json")
+    maps = ["map5.bt", "map1.bt", "map7.bt", "map3.bt", "map9.bt"]
+    worlds = [host.load_world(f, p) for f in maps]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+
+    def run(times):
+        plans = [g.clone_inputs() for g in inits]
+        sess = planner.Session(worlds, [m] * len(maps), p, plans)
+        outs = []
+        for _ in range(times):
+            sess.run(A.RBP_STAGE_ALL)
+            assert sess.download() == [0] * len(maps)
+            outs.append([g.ctrl.copy() for g in plans])
+        sess.close()
+        return outs
+
+    first, second, third = run(3)
+    monkeypatch.setenv("RBP_QP_ORDER", "0")
+    (plain,) = run(1)
+    for a, b, c, d in zip(first, second, third, plain):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a.view(np.uint64), c.view(np.uint64))
+        assert np.array_equal(a.view(np.uint64), d.view(np.uint64))
