@@ -93,17 +93,18 @@
 #define QP_EARLY_POLISH 1  // try the active-set polish before the interior-point loop has fully converged
 #endif
 // LDS doubles used by polish_qp<36>: 2 blocks + packed factor + vectors + int arrays (see qp_polish.inc)
+#include "lh_layout.h"
 #define PL_NC 256    // polish: candidate rows
 #define PL_PMAX 160  // polish: rows simultaneously active in the dual solve (wide batches; 112 on the wave path, whose
                      // workgroups are meant to share a CU's LDS in pairs)
 #define PL_PBIG 192  // second attempt of a polish whose dual solve ran out of capacity: factor in global memory (rare: ~1 batch QP in 800)
 __host__ __device__ inline int polish_pmax(int nk) { return nk <= 36 ? 112 : PL_PMAX; }
 __host__ __device__ inline size_t polish_ws_doubles(int nj, int nk) {  // cand, V, S, counters, big factor
-    return PL_NC * 14 + (size_t)(PL_NC + 1) * nj * nk + PL_NC * PL_NC + 8 + PL_PBIG * (PL_PBIG + 1) / 2;
+    return PL_NC * 14 + (size_t)(PL_NC + 1) * nj * nk + PL_NC * PL_NC + 8 + lhp_size(PL_PBIG);
 }
 __host__ __device__ inline int polish_lds_doubles(int nk) {
     const int pm = polish_pmax(nk);
-    return pm * (pm + 1) / 2 + 3 * PL_NC + 4 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
+    return lhp_size(pm) + 3 * PL_NC + 3 * pm + (pm + 2 * PL_NC + 8) / 2 + 8;
 }
 
 namespace {
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
     }
 }
 
-#ifdef QP_PROFILE  // chain-side timers of the left chain (100 MHz clock, like the phase timers): SC 25 = MFMA update, 26 = waiting for the
+#if defined(QP_PROFILE) && !defined(QP_LHSTATS)  // chain-side timers of the left chain (100 MHz clock, like the phase timers): SC 25 = MFMA update, 26 = waiting for the
                    // block assembly, 27 = the knot itself (load, factorisation, waiting for M, coupling rows)
 #define CHAIN_T0 long long ct_ = wall_clock64()
 #define CHAIN_T(slot)                                                          \
