@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
     }
 }
 
-#if defined(QP_PROFILE) && !defined(QP_LHSTATS)  // chain-side timers of the left chain (100 MHz clock, like the phase timers): SC 25 = MFMA update, 26 = waiting for the
+#if defined(QP_PROFILE) && !defined(QP_LHSTATS) && !defined(QP_SOLVE_TIMERS)  // chain-side timers of the left chain (100 MHz clock, like the phase timers): SC 25 = MFMA update, 26 = waiting for the
                    // block assembly, 27 = the knot itself (load, factorisation, waiting for M, coupling rows)
 #define CHAIN_T0 long long ct_ = wall_clock64()
 #define CHAIN_T(slot)                                                          \
@@ -1145,10 +1145,10 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
         CHAIN_T(25);
         wait_blocks(cnt, i);
         CHAIN_T(26);
+        double e0, e1, e2, x[NK];
+        coupling_coef(w, j, dir, rr, e0, e1, e2);  // (issued here: three loads from the L2, ~1 us under load, needed after the factorisation)
         if (!knot_ldl<NK>(w, j, i > 0, base, r, act, rr, P, i * (NK + 1))) ok = false;
         kl_await(Mdone, i + 1, seen);
-        double e0, e1, e2, x[NK];
-        coupling_coef(w, j, dir, rr, e0, e1, e2);
         kl_coupling_rows<NK>(x, MX, r, act, e0, e1, e2);
         CHAIN_T(27);
     }
@@ -1386,7 +1386,39 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int rr = act ? r : 0, g3 = 3 * (rr / 3), r3 = rr % 3;
     const int rs = act ? r : KL_I - 1;  // lanes >= NK write the padding slot of the small vectors
     if (wave < 2) __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);  // see twisted_factor
+    // the three coupling coefficients a chain step starts with (forward: row rr of T_{j,jp}; backward: column rr of T_{jn,j}) come from
+    // global memory: fetched ONE STEP AHEAD (the trip to the L2, ~1 us under load, was the first thing every step waited for)
+    auto step_coef = [&](int s, double& q0, double& q1, double& q2) {
+        q0 = q1 = q2 = 0.0;
+        if (ROLE != 0 || s >= nsteps || s == SF) return;
+        const int jb = wave == 0 ? left_j(s) : right_j(s);
+        if (jb < 0) return;
+        const int dir = wave == 0 ? +1 : -1;
+        if (s < SF) {
+            const bool has_prev = wave == 0 ? jb > 0 : jb + 1 < nj;
+            if (has_prev) coupling_coef(w, jb - dir, dir, rr, q0, q1, q2);
+        } else {
+            const double* E = w.Ek + 9 * (dir > 0 ? jb + 1 : jb);
+            q0 = dir > 0 ? E[3 * r3] : E[r3], q1 = dir > 0 ? E[3 * r3 + 1] : E[3 + r3], q2 = dir > 0 ? E[3 * r3 + 2] : E[6 + r3];
+        }
+    };
+    double cf0, cf1, cf2;
+    step_coef(0, cf0, cf1, cf2);
+#ifdef QP_SOLVE_TIMERS  // developer build: left chain wave, SC 25 = work of the steps, 26 = waiting at the step barrier, 27 = steps
+    long long st_ = wall_clock64();
+#define SOLVE_T(slot)                                                              \
+    do {                                                                           \
+        const long long t_ = wall_clock64();                                       \
+        if (ROLE == 0 && w.prof && tid == 0) w.prof[slot] += (double)(t_ - st_);   \
+        st_ = t_;                                                                  \
+    } while (0)
+#else
+#define SOLVE_T(slot)
+#endif
     for (int s = 0; s < nsteps; ++s) {
+        SOLVE_T(26);
+        const double e0 = cf0, e1 = cf1, e2 = cf2;
+        step_coef(s + 1, cf0, cf1, cf2);
         double* buf = lds + (s % QP_STAGE_BUFS) * STG;
         if (ROLE == 1) {
             const int sp = s + QP_STAGE_BUFS - 1;
@@ -1427,11 +1459,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 if (fwd) {
                     double v = vec[jb * NK + rr];
                     const bool has_prev = wave == 0 ? jb > 0 : jb + 1 < nj;
-                    if (has_prev) {  // r' = rhs_j - T_{j,jp} v_jp
-                        double e0, e1, e2;
-                        coupling_coef(w, jb - dir, dir, rr, e0, e1, e2);
-                        v -= e0 * V[g3] + e1 * V[g3 + 1] + e2 * V[g3 + 2];
-                    }
+                    if (has_prev) v -= e0 * V[g3] + e1 * V[g3 + 1] + e2 * V[g3 + 2];  // r' = rhs_j - T_{j,jp} v_jp
                     kl_sync();
                     A[rs] = v;
                     kl_sync();
@@ -1444,9 +1472,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                     V[rs] = vj;
                 } else {
                     // w = T_{jn,j}' x_jn: column rr of the 3x3 block of its (agent, dim) group, rows g3 .. g3+2 (x_jn sits in V)
-                    const double* E = w.Ek + 9 * (dir > 0 ? jb + 1 : jb);
-                    const double c0 = dir > 0 ? E[3 * r3] : E[r3], c1 = dir > 0 ? E[3 * r3 + 1] : E[3 + r3], c2 = dir > 0 ? E[3 * r3 + 2] : E[6 + r3];
-                    const double wv = c0 * V[g3] + c1 * V[g3 + 1] + c2 * V[g3 + 2];
+                    const double wv = e0 * V[g3] + e1 * V[g3 + 1] + e2 * V[g3 + 2];
                     kl_sync();
                     A[rs] = wv;
                     kl_sync();
@@ -1460,6 +1486,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 }
             }
         }
+        SOLVE_T(25);
         __syncthreads();
     }
     if (wave < 2) __builtin_amdgcn_s_setprio(0);
