@@ -695,20 +695,25 @@ __device__ void apply_FT(const QpDims& d, const QpWs& w, const double* cvec, dou
             out[(size_t)(j - 1) * d.nk + u * 3 + e] = scale * (xr[e] + L[0 + e] * xl[0] + L[3 + e] * xl[1] + L[6 + e] * xl[2]);
     }
 }
-// dx[a][k][j6] = F du   (pinned control points get 0)
+// dx[a][k][j6] = F du   (pinned control points get 0).  One work item per (knot, agent, dim): its three reduced values feed the six
+// control points around the knot -- 420 items with a dozen independent loads each for a batch of four, two rounds of the workgroup,
+// where a loop over the 2592 control-space entries was ten rounds of one load-wait-store each (~1 us per round under load).
 __device__ void apply_F(const QpDims& d, const QpWs& w, const double* du, double* dx) {
     const int oq = d.oq, nu = 3 * d.nb;
-    for (int it = threadIdx.x; it < nu * oq; it += QP_THREADS) {
-        const int u = it / oq, j6 = it % oq, m = j6 / 6, i = j6 % 6;
-        double v = 0;
-        if (i < 3) {
-            if (m >= 1) v = du[(size_t)(m - 1) * d.nk + u * 3 + i];
-        } else if (m + 1 < d.M) {
-            const double* L = w.Lk + 9 * (m + 1) + 3 * (i - 3);
-            const double* uu = du + (size_t)m * d.nk + u * 3;
-            v = L[0] * uu[0] + L[1] * uu[1] + L[2] * uu[2];
-        }
-        dx[it] = v;
+    for (int it = threadIdx.x; it < d.nj * nu; it += QP_THREADS) {
+        const int j = it / nu + 1, u = it % nu;
+        const double* uu = du + (size_t)(j - 1) * d.nk + u * 3;
+        const double* L = w.Lk + 9 * j;
+        const double u0 = uu[0], u1 = uu[1], u2 = uu[2];
+        double* o = dx + (size_t)u * oq + 6 * (j - 1) + 3;  // control points 6(j-1)+3 .. 6j+2
+        o[0] = L[0] * u0 + L[1] * u1 + L[2] * u2;
+        o[1] = L[3] * u0 + L[4] * u1 + L[5] * u2;
+        o[2] = L[6] * u0 + L[7] * u1 + L[8] * u2;
+        o[3] = u0, o[4] = u1, o[5] = u2;
+    }
+    for (int it = threadIdx.x; it < nu * 6; it += QP_THREADS) {  // the pinned ends
+        const int u = it / 6, q = it % 6;
+        dx[(size_t)u * oq + (q < 3 ? q : oq - 6 + q)] = 0.0;
     }
 }
 
@@ -1330,7 +1335,17 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
     double* vec = lds + QP_STAGE_BUFS * STG;           // nj*NK: rhs -> z -> x
     double* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KL_I]
-    for (int i = tid; i < nj * NK; i += QP_THREADS) vec[i] = rhs[i];
+    {  // rhs -> LDS: every thread's loads first, then its stores (one trip to memory instead of one per round; see apply_F)
+        constexpr int RQ = 4;
+        for (int i0 = tid; i0 < nj * NK; i0 += RQ * QP_THREADS) {
+            double t[RQ];
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) t[q] = i0 + q * QP_THREADS < nj * NK ? rhs[i0 + q * QP_THREADS] : 0.0;
+#pragma unroll
+            for (int q = 0; q < RQ; ++q)
+                if (i0 + q * QP_THREADS < nj * NK) vec[i0 + q * QP_THREADS] = t[q];
+        }
+    }
     for (int i = tid; i < KS::VECS; i += QP_THREADS) small[i] = 0.0;
     // block indices handled at step s by the left / right wave (-1: idle)
     auto left_j = [&](int s) { return s < SF ? (s - (SF - nl) >= 0 ? s - (SF - nl) : -1) : (s == SF ? mid : (mid - 1 - (s - SF - 1) >= 0 ? mid - 1 - (s - SF - 1) : -1)); };
@@ -2394,9 +2409,22 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         double applied = 0;
         for (int bt = 0; bt < 40; ++bt) {
             const double delta = alpha - applied;
-            for (int i = tid; i < d.nb * 3 * d.oq; i += QP_THREADS) {
-                const int a = i / (3 * d.oq), rest = i % (3 * d.oq);
-                ctrl[((size_t)(first + a) * 3) * d.oq + rest] += delta * w.dx[i];
+            {  // (the batch agents' control points are contiguous: [first .. first + nb) x 3 x oq; four entries per thread and round, loads first)
+                double* xb = ctrl + (size_t)first * 3 * d.oq;
+                const int nx = d.nb * 3 * d.oq;
+                for (int i0 = tid; i0 < nx; i0 += 4 * QP_THREADS) {
+                    double xv[4], dv4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = i0 + q * QP_THREADS;
+                        xv[q] = i < nx ? xb[i] : 0.0, dv4[q] = i < nx ? w.dx[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = i0 + q * QP_THREADS;
+                        if (i < nx) xb[i] = xv[q] + delta * dv4[q];
+                    }
+                }
             }
             __threadfence_block();
             __syncthreads();
