@@ -2134,22 +2134,44 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const double* hi = w.boxhi + ((size_t)a * M + seg) * 3;
         int cnt = 0;
         int* fl = w.flist + (size_t)it * N;
-        for (int f = 0; f < N; ++f) {
-            if (f >= first && f < first + nb) continue;
-            const bool a_first = qa < f;
-            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
-            const double sg = a_first ? 1.0 : -1.0;
-            const double n0 = sg * (double)nv[0], n1 = sg * (double)nv[1], n2 = sg * (double)nv[2];
-            const double mx = fmax(n0 * lo[0], n0 * hi[0]) + fmax(n1 * lo[1], n1 * hi[1]) + fmax(n2 * lo[2], n2 * hi[2]);
-            const double rr = ra + c.radius[f];
-            bool keep = false;
-            for (int i = 0; i < 6; ++i) {
-                const int j6 = 6 * seg + i;
-                const double nd = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
-                                  n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6];
-                if (!(nd - rr - mx > 1e-6)) keep = true;
+        // (four neighbours per round, all their loads ahead of the list stores: the compiler does not move a load across a store, and a
+        // neighbour per round meant 60 trips to memory in a row, ~1 us each under load)
+        for (int f0 = 0; f0 < N && N > 1; f0 += 4) {
+            bool keep4[4];
+            float nvq[4][3];
+            double cf[4][6][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = f0 + q < N ? f0 + q : N - 1;
+                const bool a_first = qa < f;
+                const int lo_ = a_first ? qa : f, hi_ = a_first ? f : qa;
+                const float* nv = c.normals + (pair_index(N, lo_ == hi_ ? 0 : lo_, lo_ == hi_ ? 1 : hi_) * M + seg) * 3;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) nvq[q][e] = nv[e];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) cf[q][i][e] = ctrl[((size_t)f * 3 + e) * d.oq + 6 * seg + i];
             }
-            if (keep) fl[cnt++] = f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = f0 + q;
+                const bool a_first = qa < f;
+                const double sg = a_first ? 1.0 : -1.0;
+                const double n0 = sg * (double)nvq[q][0], n1 = sg * (double)nvq[q][1], n2 = sg * (double)nvq[q][2];
+                const double mx = fmax(n0 * lo[0], n0 * hi[0]) + fmax(n1 * lo[1], n1 * hi[1]) + fmax(n2 * lo[2], n2 * hi[2]);
+                const double rr = ra + c.radius[f < N ? f : 0];
+                bool keep = false;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double nd = n0 * cf[q][i][0] + n1 * cf[q][i][1] + n2 * cf[q][i][2];
+                    if (!(nd - rr - mx > 1e-6)) keep = true;
+                }
+                keep4[q] = keep && f < N && !(f >= first && f < first + nb);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (keep4[q]) fl[cnt++] = f0 + q;
         }
         w.fcnt[it] = cnt;
     }
@@ -2210,15 +2232,30 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         const size_t r0 = (size_t)w.tile_base[wi >> 6] + (wi & 63) + (size_t)d.ncol0 * 64;
         float* nr = w.nrm + (size_t)w.fbase[as] * 3;
         const double ra = c.radius[qa];
-        for (int idx = 0; idx < cnt; ++idx) {
-            const int f = fl[idx];
-            const bool a_first = qa < f;
-            const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
-            const float sgf = a_first ? 1.0f : -1.0f;
-            const double n0 = (double)(sgf * nv[0]), n1 = (double)(sgf * nv[1]), n2 = (double)(sgf * nv[2]);
-            if (i == 0) nr[3 * idx] = sgf * nv[0], nr[3 * idx + 1] = sgf * nv[1], nr[3 * idx + 2] = sgf * nv[2];
-            w.rh[r0 + (size_t)idx * 64] = n0 * ctrl[((size_t)f * 3 + 0) * d.oq + j6] + n1 * ctrl[((size_t)f * 3 + 1) * d.oq + j6] +
-                                          n2 * ctrl[((size_t)f * 3 + 2) * d.oq + j6] - (ra + c.radius[f]);
+        for (int i0 = 0; i0 < cnt; i0 += 4) {  // (four rows per round, loads first: see the presolve loop)
+            int fq[4];
+            float nvq[4][3];
+            double cfq[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fq[q] = fl[i0 + q < cnt ? i0 + q : cnt - 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = fq[q];
+                const bool a_first = qa < f;
+                const float* nv = c.normals + (pair_index(N, a_first ? qa : f, a_first ? f : qa) * M + seg) * 3;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) nvq[q][e] = nv[e], cfq[q][e] = ctrl[((size_t)f * 3 + e) * d.oq + j6];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = i0 + q, f = fq[q];
+                if (idx < cnt) {
+                    const float sgf = qa < f ? 1.0f : -1.0f;
+                    const double n0 = (double)(sgf * nvq[q][0]), n1 = (double)(sgf * nvq[q][1]), n2 = (double)(sgf * nvq[q][2]);
+                    if (i == 0) nr[3 * idx] = sgf * nvq[q][0], nr[3 * idx + 1] = sgf * nvq[q][1], nr[3 * idx + 2] = sgf * nvq[q][2];
+                    w.rh[r0 + (size_t)idx * 64] = n0 * cfq[q][0] + n1 * cfq[q][1] + n2 * cfq[q][2] - (ra + c.radius[f]);
+                }
+            }
         }
     }
     __threadfence_block();
