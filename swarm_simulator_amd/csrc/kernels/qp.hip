@@ -2089,24 +2089,45 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     init_block_pads(d, w);
 
     // SFC box of every (batch agent, segment): first box with end time >= T[m+1]  (rbp_planner.hpp:447-453)
-    for (int a = tid; a < nb; a += QP_THREADS) {
-        const int qa = first + a;
-        int nbx = S.sfc_count[(size_t)mission * N + qa];
-        if (nbx <= 0) {  // no SFC boxes: the planner stage was run on a plan whose corridor was never computed (caller error)
-            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_BAD_ARGUMENT);
-            nbx = 1;  // keeps the reads below inside the agent's slot; the mission is abandoned after the barrier
+    // (the box end times go through LDS: the scan below is a chain of dependent reads -- four threads, ~40 steps each --, and from
+    // global memory every step was a trip of its own; the boxes themselves are then copied by all threads at once)
+    {
+        const int need = nb * S.max_boxes + (M + 2) + (nb * M + 1) / 2 + 1;
+        const bool stage = need <= c.lds_avail;          // (wide batches of the tiled path: straight from global memory)
+        double* bt_l = lds;                              // [nb][max_boxes]
+        double* T_l = lds + nb * S.max_boxes;            // [M + 1]
+        int* sel_l = stage ? (int*)(T_l + M + 2) : w.fcnt;  // [nb][M]  (fcnt is filled by the presolve below)
+        if (stage) {
+            for (int it = tid; it < nb * S.max_boxes; it += QP_THREADS)
+                bt_l[it] = S.sfc_time[((size_t)mission * N + first + it / S.max_boxes) * S.max_boxes + it % S.max_boxes];
+            for (int it = tid; it <= M; it += QP_THREADS) T_l[it] = T[it];
+            __syncthreads();
         }
-        const double* bt = S.sfc_time + ((size_t)mission * N + qa) * S.max_boxes;
-        const double* bx = S.sfc_box + ((size_t)mission * N + qa) * S.max_boxes * 6;
-        int bi = 0;
-        for (int m = 0; m < M; ++m) {
-            while (bi < nbx && bt[bi] < T[m + 1]) bi++;
-            const int sel = bi < nbx ? bi : nbx - 1;
-            for (int k = 0; k < 3; ++k) {
-                w.boxlo[((size_t)a * M + m) * 3 + k] = bx[6 * sel + k];
-                w.boxhi[((size_t)a * M + m) * 3 + k] = bx[6 * sel + 3 + k];
+        for (int a = tid; a < nb; a += QP_THREADS) {
+            const int qa = first + a;
+            int nbx = S.sfc_count[(size_t)mission * N + qa];
+            if (nbx <= 0) {  // no SFC boxes: the planner stage was run on a plan whose corridor was never computed (caller error)
+                atomicCAS(&S.status[mission], 0, (int)RBP_ERR_BAD_ARGUMENT);
+                nbx = 1;  // keeps the reads below inside the agent's slot; the mission is abandoned after the barrier
+            }
+            const double* bt = stage ? bt_l + a * S.max_boxes : S.sfc_time + ((size_t)mission * N + qa) * S.max_boxes;
+            const double* Tt = stage ? T_l : T;
+            int bi = 0;
+            for (int m = 0; m < M; ++m) {
+                while (bi < nbx && bt[bi] < Tt[m + 1]) bi++;
+                sel_l[a * M + m] = bi < nbx ? bi : nbx - 1;
             }
         }
+        __threadfence_block();
+        __syncthreads();
+        for (int it = tid; it < nb * M * 3; it += QP_THREADS) {
+            const int am = it / 3, k = it % 3, a = am / M;
+            const double* bx = S.sfc_box + ((size_t)mission * N + first + a) * S.max_boxes * 6 + 6 * sel_l[am];
+            w.boxlo[(size_t)am * 3 + k] = bx[k];
+            w.boxhi[(size_t)am * 3 + k] = bx[3 + k];
+        }
+        __threadfence_block();
+        __syncthreads();
     }
     // pin the six end control points of the batch agents to the start/goal state (rows 0-5 of Aeq_base, :380-387)
     for (int it = tid; it < nb * 3; it += QP_THREADS) {
@@ -2177,15 +2198,17 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0, free_rows = 0;
-        for (int it = 0; it < nb * M; ++it) {
-            w.fbase[it] = acc;
-            acc += w.fcnt[it];
-            const int seg = it % M;
-            free_rows += w.fcnt[it] * ((seg == 0 || seg == M - 1) ? (M == 1 ? 0 : 3) : 6);
-        }
-        *flag = free_rows;
+    // offsets of the groups' normal lists (exclusive prefix sum of the counts) and the number of non-constant frozen rows: every group
+    // sums its predecessors itself -- loads only, all in flight together; one thread walking the 144 groups with a store per step made
+    // 144 trips to memory in a row
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int it = tid; it < nb * M; it += QP_THREADS) {
+        int acc = 0;
+        for (int o = 0; o < it; ++o) acc += w.fcnt[o];
+        w.fbase[it] = acc;
+        const int seg = it % M;
+        atomicAdd(flag, w.fcnt[it] * ((seg == 0 || seg == M - 1) ? (M == 1 ? 0 : 3) : 6));
     }
     __threadfence_block();
     __syncthreads();
@@ -2208,13 +2231,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     __syncthreads();
     // row storage (see the note above QpWs): tile t holds the control points wi = 64 t .. 64 t + 63; its columns are as long as
     // its first (= longest) one
-    if (tid == 0) {
+    for (int t = tid; t <= d.ntile; t += QP_THREADS) {  // (every tile sums its predecessors: see fbase above)
         int base = 0;
-        for (int t = 0; t < d.ntile; ++t) {
-            w.tile_base[t] = base;
-            base += 64 * (d.ncol0 + w.fcnt[w.fperm[(64 * t) / 6]]);
-        }
-        w.tile_base[d.ntile] = base;
+        for (int o = 0; o < t; ++o) base += 64 * (d.ncol0 + w.fcnt[w.fperm[(64 * o) / 6]]);
+        w.tile_base[t] = base;
     }
     for (int wi = tid; wi < nb * d.oq; wi += QP_THREADS) {
         const int grp = w.fperm[wi / 6], a = grp / M, seg = grp - a * M;
