@@ -83,6 +83,9 @@
 #ifndef QP_RCP_NEWTON
 #define QP_RCP_NEWTON 2
 #endif
+#ifndef QP_T_WRITE_FULL
+#define QP_T_WRITE_FULL 0  // LDS-staged assembly: 1 = whole rows of T_j leave for global memory, 0 = the half the factorisation reads
+#endif
 #ifndef QP_EARLY_TRIES
 #define QP_EARLY_TRIES 2
 #endif
@@ -941,9 +944,9 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
         kl_sync();
         double* Tg = A.Td + (size_t)j * nk * nk;
         if ((nk & 1) == 0) {
-            for (int idx = lane; idx < nk * nk / 2; idx += 64) {
+            for (int idx = lane; idx < nk * nk / 2; idx += 64) {  // (the factorisation uses the entries (r, k >= r) only: knot_ldl)
                 const int r = (2 * idx) / nk, k2 = (2 * idx) % nk;
-                *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
+                if (QP_T_WRITE_FULL || k2 + 1 >= r) *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
             }
         } else {
             for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
