@@ -897,6 +897,15 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
         tA[u] = ai, tB[u] = ai + tc - (ai * n3 - ai * (ai - 1) / 2);
         if (t < per) ntile = u + 1;
     }
+    const int row0 = (2 * lane) / nk, col0 = (2 * lane) % nk, drow = 128 / nk, dcol = 128 % nk;  // see the row copy below
+    size_t nr_off = 0;  // this lane's entry of the pairs' normals (pair, left / right segment, component): the same for every knot
+    if (lane < 6 * npb) {
+        const int pw = lane / 6, sg = (lane / 3) % 2, c3 = lane % 3;
+        int lo = 0, rest = pw;  // pair pw = (lo, hi) in the order lo * nb - lo (lo + 1) / 2 + (hi - lo - 1)
+        while (rest >= nb - 1 - lo) rest -= nb - 1 - lo, lo++;
+        const int hi = lo + 1 + rest;
+        nr_off = (pair_index(A.N, A.first + lo, A.first + hi) * A.M + sg) * 3 + c3;
+    }
     for (int j = wave; j < nj; j += NW) {
         const int jn = j + 1, j60 = 6 * j + 3;  // first control point of the knot
         for (int idx = lane; idx < nb * 36; idx += 64) {
@@ -904,13 +913,7 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
             Sin[idx] = A.cpacc[(size_t)e * ncp + (size_t)a * oq + j60 + pp];
         }
         for (int idx = lane; idx < 6 * npb; idx += 64) Pw[idx] = A.pwgt[(size_t)(idx / 6) * oq + j60 + idx % 6];
-        for (int idx = lane; idx < 6 * npb; idx += 64) {
-            const int pw = idx / 6, sg = (idx / 3) % 2, c3 = idx % 3;
-            int lo = 0, rest = pw;  // pair pw = (lo, hi) in the order lo * nb - lo (lo + 1) / 2 + (hi - lo - 1)
-            while (rest >= nb - 1 - lo) rest -= nb - 1 - lo, lo++;
-            const int hi = lo + 1 + rest;
-            Nr[idx] = (double)A.normals[(pair_index(A.N, A.first + lo, A.first + hi) * A.M + (j + sg)) * 3 + c3];
-        }
+        if (lane < 6 * npb) Nr[lane] = (double)A.normals[nr_off + (size_t)j * 3];  // (6 npb <= 36: one entry per lane)
         double L[9], Dk[9];
 #pragma unroll
         for (int e = 0; e < 9; ++e) L[e] = A.Lk[9 * jn + e], Dk[e] = A.Dk[9 * jn + e];
@@ -944,9 +947,14 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
         kl_sync();
         double* Tg = A.Td + (size_t)j * nk * nk;
         if ((nk & 1) == 0) {
-            for (int idx = lane; idx < nk * nk / 2; idx += 64) {  // (the factorisation uses the entries (r, k >= r) only: knot_ldl)
-                const int r = (2 * idx) / nk, k2 = (2 * idx) % nk;
+            // (the factorisation uses the entries (r, k >= r) only: knot_ldl.  Row and column of a lane's pair advance by 128 elements
+            // per round: carried along, not divided out -- nk is not a compile-time constant here, and two integer divisions per pair
+            // were more instructions than everything else in this loop)
+            int r = row0, k2 = col0;
+            for (int idx = lane; idx < nk * nk / 2; idx += 64) {
                 if (QP_T_WRITE_FULL || k2 + 1 >= r) *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
+                r += drow, k2 += dcol;
+                if (k2 >= nk) k2 -= nk, r++;
             }
         } else {
             for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
