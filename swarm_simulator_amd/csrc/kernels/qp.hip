@@ -878,11 +878,14 @@ __device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
 // instruction).  Tile by tile from / to global memory a knot costs ~10^4 scattered 8-byte transactions, this way ~10^2 line requests --
 // and under load the memory system is bound by transactions (see the row sweeps).  lds: QP_THREADS / 64 scratch areas of ASML_DOUBLES.
 #define ASML_DOUBLES(nk, nb) ((nk) * KL_LD + (nb) * 36 + 3 * (nb) * ((nb) - 1) + 3 * (nb) * ((nb) - 1) + 8)
-__device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
+// One wave, a sequence of knots: next() returns the next knot (0-based) or -1, done(j) is called when T_j is on its way to global memory.
+// scratch: ASML_DOUBLES(nk, nb) doubles of LDS of the wave's own.
+template <class NextFn, class DoneFn>
+__device__ __forceinline__ void assemble_knots_lds(const AsmArgs& A, double* scratch, NextFn next, DoneFn done) {
     const int nb = A.nb, oq = A.oq, nk = 9 * nb, npb = nb * (nb - 1) / 2, n3 = 3 * nb, per = n3 * (n3 + 1) / 2;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, NW = QP_THREADS / 64;
+    const int lane = threadIdx.x & 63;
     const size_t ncp = (size_t)nb * oq;
-    kl_lds* Timg = (kl_lds*)(lds + (size_t)wave * ASML_DOUBLES(nk, nb));
+    kl_lds* Timg = (kl_lds*)scratch;
     kl_lds* Sin = Timg + nk * KL_LD;  // [a][sym][p]
     kl_lds* Pw = Sin + nb * 36;      // [pair][p]
     kl_lds* Nr = Pw + 6 * npb;       // [pair][left / right segment][3]
@@ -906,7 +909,7 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
         const int hi = lo + 1 + rest;
         nr_off = (pair_index(A.N, A.first + lo, A.first + hi) * A.M + sg) * 3 + c3;
     }
-    for (int j = wave; j < nj; j += NW) {
+    for (int j = next(); j >= 0; j = next()) {
         const int jn = j + 1, j60 = 6 * j + 3;  // first control point of the knot
         for (int idx = lane; idx < nb * 36; idx += 64) {
             const int a = idx / 36, e = (idx / 6) % 6, pp = idx % 6;
@@ -959,8 +962,15 @@ __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
         } else {
             for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
         }
+        done(j);
         kl_sync();
     }
+}
+// all knots up front, one wave per knot in turn (256-thread build).  lds: QP_THREADS / 64 scratch areas.
+__device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
+    const int wave = threadIdx.x >> 6, NW = QP_THREADS / 64;
+    int j = wave - NW;
+    assemble_knots_lds(A, lds + (size_t)wave * ASML_DOUBLES(9 * A.nb, A.nb), [&] { j += NW; return j < nj ? j : -1; }, [](int) {});
 }
 
 __device__ inline AsmArgs asm_args(const RowCtx& c) {
@@ -1019,8 +1029,8 @@ __device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
 // Progress counters of the just-in-time block assembly (LDS ints behind the two chain areas): cnt[i] counts the helper waves that
 // have finished the blocks of chain step i; a chain may load its i-th block when all QP_THREADS/64 - 2 of them have.
 // Wave roles of the wave path's factorisation: 0, 1 = the two chains; 2, 3 = their companions (M = L^-T behind the chain, see
-// wave_factor_follow); the 512-thread build has four more waves, which assemble the knot blocks; in the 256-thread build the
-// companions assemble the next step's blocks after each M.
+// wave_factor_follow); the 512-thread build has four more waves, which assemble the knot blocks behind the chains (one wave per block,
+// through the LDS: assemble_knots_lds); the 256-thread build assembles all blocks up front (assemble_blocks_lds).
 #define ASM_WAVE0 4                                                        // first assembling wave
 #define ASM_HELPERS (QP_THREADS / 64 > ASM_WAVE0 ? QP_THREADS / 64 - ASM_WAVE0 : 0)   // assembling waves
 __device__ __forceinline__ void wait_blocks(int* cnt, int i) {
@@ -1217,23 +1227,34 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
         if (wave == 1 && nr > 0) ok = wave_factor_chain<NK>(d, w, d.nj - 1, nr, -1, lds + AREA, cnt, 1);
         if (wave == 1) __builtin_amdgcn_s_setprio(0);
     }
-    const AsmArgs A = *asmb;
-    const int per_knot = A.nb * A.nb * 9, ht = threadIdx.x - 64 * ASM_WAVE0, HT = QP_THREADS - 64 * ASM_WAVE0;
-    auto assemble_step = [&](int i) {
-        if (i < SF) {
-            // first half of the assembling threads: the left chain's block i; second half: the right chain's block nj-1-i
-            const int half = HT / 2, side = ht >= half, t0 = side ? ht - half : ht;
-            const int blk = side ? d.nj - 1 - i : i;
-            if (side ? i < nr : i < nl)
-                for (int it = t0; it < per_knot; it += half) assemble_item(A, nullptr, blk + 1, it, true);
-        } else {
-            for (int it = ht; it < per_knot; it += HT) assemble_item(A, nullptr, mid + 1, it, true);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
     if (ROLE == 1) {
-        for (int i = 0; i <= SF; ++i) assemble_step(i);
+        // assembling waves (512-thread build): through the LDS like the 256-thread build's up-front assembly (assemble_knots_lds), one
+        // wave per block.  Waves 4, 5 take the left / right chain's block of the even steps, waves 6, 7 those of the odd steps (two
+        // chain steps of time per block); a wave announces its block by adding ASM_HELPERS / 2 to the step's counter, so that
+        // wait_blocks sees ASM_HELPERS when both blocks of a step are out.  The middle block (step SF) is wave 4's / 6's.
+        const AsmArgs A = *asmb;
+        const int hw = (threadIdx.x >> 6) - ASM_WAVE0, side = hw & 1, par = hw >> 1;  // par: parity of the steps this wave serves
+        double* scratch = lds + 2 * AREA + 128 + (size_t)hw * ASML_DOUBLES(NK, (NK / 9));
+        int i = par - 2;
+        assemble_knots_lds(
+            A, scratch,
+            [&] {
+                for (i += 2; i <= SF; i += 2) {
+                    if (i < SF) {
+                        if (side ? i < nr : i < nl) return side ? d.nj - 1 - i : i;
+                    } else if (side == 0)
+                        return mid;
+                    // nothing to assemble for this wave at step i: announce it all the same
+                    if ((threadIdx.x & 63) == 0)
+                        __hip_atomic_fetch_add(cnt + i, i < SF ? ASM_HELPERS / 2 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                return -1;
+            },
+            [&](int) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if ((threadIdx.x & 63) == 0)
+                    __hip_atomic_fetch_add(cnt + i, i < SF ? ASM_HELPERS / 2 : ASM_HELPERS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            });
     }
     if (ROLE == 2) {
         // companion of chain `wave`: M_j behind the chain's factorisation of block j
@@ -2816,7 +2837,8 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
         lds = std::max(lds, sizeof(double) * ((size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KL_I + 64));  // solve_staged
-        lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 64 + 32) + 16);  // chain areas + assembly progress counters
+        // chain areas + assembly progress counters (+ the assembling waves' LDS scratch in the 512-thread build)
+        lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + ASM_HELPERS * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
         if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
             const size_t lb = (size_t)((nk + 15) & ~15);
             lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
