@@ -86,6 +86,9 @@
 #ifndef QP_T_WRITE_FULL
 #define QP_T_WRITE_FULL 0  // LDS-staged assembly: 1 = whole rows of T_j leave for global memory, 0 = the half the factorisation reads
 #endif
+#ifndef QP_MID_FOLLOW
+#define QP_MID_FOLLOW (QP_THREADS >= 512)  // see wave_factor_mid
+#endif
 #ifndef QP_EARLY_TRIES
 #define QP_EARLY_TRIES 2
 #endif
@@ -1193,10 +1196,16 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     if (mid > 0) kl_syrk<NK>(bl + A::MX, bl + A::I, bl + A::C, r, false), nsy++;
     if (mid + 1 < d.nj) kl_syrk<NK>(br + A::MX, br + A::I, bl + A::C, r, nsy > 0), nsy++;
     wait_blocks(cnt, cnt_idx);
-    int seen = 0;
-    kl_ldsi* scratch = CHAIN_SYNC(cnt, 2);  // (nobody follows the middle block: the wave computes M itself)
+    // progress words of the middle block.  512-thread build: its M is computed by the left chain's companion wave, like every other
+    // block's (twisted_factor, ROLE 2) -- on the chain wave it is ~10 k cycles more at the end of every factorisation: one mission
+    // 122.4 -> 121.1 ms.  With two workgroups per CU the polling companion costs the neighbour more than it saves (-1.3 % at 2000
+    // resident, A/B on one box): the 256-thread build keeps M on the chain wave.
+    kl_ldsi* scratch = CHAIN_SYNC(cnt, 2);
     const bool ok = knot_ldl<NK>(w, mid, nsy > 0, bl, r, act, rr, scratch, 0);
-    knot_inverse<NK, false>(w, mid, bl, r, act, scratch, 0, seen, scratch, 0);
+    if (!QP_MID_FOLLOW) {
+        int seen = 0;
+        knot_inverse<NK, false>(w, mid, bl, r, act, scratch, 0, seen, scratch, 0);
+    }
     return ok;
 }
 
@@ -1272,6 +1281,12 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     if (ROLE == 0 && wave == 0) {
         if (!wave_factor_mid<NK>(d, w, lds, lds + AREA, cnt, SF) && threadIdx.x == 0) *flag = 1;
         __builtin_amdgcn_s_setprio(0);
+    }
+    if (QP_MID_FOLLOW && ROLE == 2 && wave == 0) {  // M of the middle block, behind wave_factor_mid's factorisation
+        const int r = threadIdx.x & 63;
+        int seen = 0;
+        kl_ldsi* P = CHAIN_SYNC(cnt, 2);
+        knot_inverse<NK, true>(w, mid, (kl_lds*)lds, r, r < NK, P, 0, seen, P + 1, 1);
     }
     __threadfence_block();
     __syncthreads();
