@@ -1303,74 +1303,87 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
 // waves 0 / 1 run step s of the left / right chain.  rhs -> z -> x lives in LDS throughout (vec).
 // ROLE: 0 = compiled for the two chain waves, 1 = for the staging waves (2..): two __noinline__ functions (solve_entry_*), so that the
 // staging waves -- a dozen registers -- have no prologue saving callee-saved VGPRs.
-#ifndef KS_CH
-#define KS_CH 12  // k-chunk of the products: loads of the next chunk are issued ahead of the arithmetic of the current one
-#endif
-
-// sum_k Mst[k][rr] * b[k]  (column rr of the staged matrix: consecutive lanes read consecutive addresses)
+// The two products of a chain step use M_j's triangle with ALL 64 lanes: a lane owns a PIECE -- KsPieces::CH consecutive terms of one row
+// (or column) -- instead of a whole row, of which only NK <= 36 exist and whose lower half is zeros: 15 loads and multiply-adds per
+// lane instead of 36, then the up to three pieces of a row meet through 64 doubles of LDS.  Chunk t of the product by rows covers the
+// columns NK - CH (t + 1) .. NK - 1 - CH t (anchored at the right edge: row r needs the chunks with NK - 1 - CH t >= r), chunk t of the
+// product by columns the rows CH t .. CH t + CH - 1 (anchored at the top: column c needs the chunks with CH t <= c).  Terms that fall
+// left of / below the diagonal multiply the stage buffers' zeros, terms outside the block multiply the zero padding of the VECTOR (KS_VPAD
+// slots either side; whatever finite number sits at the matrix address): no masks, no branches.
+#define KS_VPAD 16                       // zero slots either side of a chain vector
+#define KS_VLEN (KS_VPAD + KL_I + KS_VPAD)  // doubles per vector (the slot NK + 12 takes the writes of the lanes without a row)
 template <int NK>
-__device__ __forceinline__ double kl_matvec_cols(const kl_lds* Mst, const kl_lds* b, int rr) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    double mc[2][KS_CH];
-    kl_d2 bc[2][KS_CH / 2];
-#pragma unroll
-    for (int q = 0; q < KS_CH; ++q)
-        if (q < NK) mc[0][q] = Mst[q * KL_LD + rr];
-#pragma unroll
-    for (int q = 0; q < KS_CH / 2; ++q)
-        if (2 * q < NK) bc[0][q] = *(const kl_lds2*)(b + 2 * q);
-#pragma unroll
-    for (int ch = 0; ch * KS_CH < NK; ++ch) {
-        const int kn = (ch + 1) * KS_CH;
-#pragma unroll
-        for (int q = 0; q < KS_CH; ++q)
-            if (kn + q < NK) mc[(ch + 1) & 1][q] = Mst[(kn + q) * KL_LD + rr];
-#pragma unroll
-        for (int q = 0; q < KS_CH / 2; ++q)
-            if (kn + 2 * q < NK) bc[(ch + 1) & 1][q] = *(const kl_lds2*)(b + kn + 2 * q);
-#pragma unroll
-        for (int q = 0; q < KS_CH; q += 4) {
-            const int k = ch * KS_CH + q;
-            if (k < NK) s0 += mc[ch & 1][q] * bc[ch & 1][q / 2][0];
-            if (k + 1 < NK) s1 += mc[ch & 1][q + 1] * bc[ch & 1][q / 2][1];
-            if (k + 2 < NK) s2 += mc[ch & 1][q + 2] * bc[ch & 1][q / 2 + 1][0];
-            if (k + 3 < NK) s3 += mc[ch & 1][q + 3] * bc[ch & 1][q / 2 + 1][1];
-        }
+struct KsPieces {
+    static constexpr int CH = (NK * 15 + 35) / 36;  // 36 -> 15, 27 -> 12, 18 -> 8, 9 -> 4
+    static constexpr int N0 = NK, N1 = NK - CH > 0 ? NK - CH : 0, N2 = NK - 2 * CH > 0 ? NK - 2 * CH : 0;
+    static_assert(NK - 3 * CH <= 0 && N0 + N1 + N2 <= 64, "three chunks, one wavefront");
+    static_assert(3 * CH - NK <= KS_VPAD && 3 * CH - 1 - (NK - 1) <= KS_VPAD, "vector padding");
+    __device__ static __forceinline__ void of_lane(int lane, int& idx, int& t) {
+        t = lane < N0 ? 0 : (lane < N0 + N1 ? 1 : 2);
+        idx = lane < N0 ? lane : (lane < N0 + N1 ? lane - N0 : (lane < N0 + N1 + N2 ? lane - N0 - N1 : 0));
     }
-    return (s0 + s1) + (s2 + s3);
+};
+// sum_k Mst[k][c] * b[k] for column c = rr (lanes rr < NK; b: vector base, i.e. entry 0); psum: 64 doubles of scratch
+template <int NK>
+__device__ __forceinline__ double kl_matvec_cols(const kl_lds* Mst, const kl_lds* b, kl_lds* psum, int lane) {
+    using P = KsPieces<NK>;
+    int idx, t;
+    P::of_lane(lane, idx, t);
+    const int k0 = P::CH * t, c = k0 + idx;
+    const kl_lds* mp = Mst + k0 * KL_LD + c;
+    const kl_lds* bp = b + k0;
+    double mv[P::CH], bv[P::CH];
+#pragma unroll
+    for (int j = 0; j < P::CH; ++j) mv[j] = mp[j * KL_LD], bv[j] = bp[j];
+    double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int j = 0; j < P::CH; ++j) {
+        if (j % 3 == 0) s0 += mv[j] * bv[j];
+        if (j % 3 == 1) s1 += mv[j] * bv[j];
+        if (j % 3 == 2) s2 += mv[j] * bv[j];
+    }
+    psum[lane] = (s0 + s1) + s2;
+    kl_sync();
+    const int cc = lane < NK ? lane : 0;
+    double r = psum[cc];
+    if (P::N1 > 0) r += cc >= P::CH ? psum[P::N0 + cc - P::CH] : 0.0;
+    if (P::N2 > 0) r += cc >= 2 * P::CH ? psum[P::N0 + P::N1 + cc - 2 * P::CH] : 0.0;
+    return r;
 }
-
-// sum_k Mst[rr][k] * b[k]  (row rr of the staged matrix: 16-byte loads per lane, rows KL_LD apart are conflict free)
+// sum_k Mst[r][k] * b[k] for row r = rr
 template <int NK>
-__device__ __forceinline__ double kl_matvec_rows(const kl_lds* Mst, const kl_lds* b, int rr) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    const kl_lds* row = Mst + rr * KL_LD;
-    kl_d2 mc[2][KS_CH / 2], bc[2][KS_CH / 2];
+__device__ __forceinline__ double kl_matvec_rows(const kl_lds* Mst, const kl_lds* b, kl_lds* psum, int lane) {
+    using P = KsPieces<NK>;
+    int idx, t;
+    P::of_lane(lane, idx, t);
+    const int k0 = NK - P::CH * (t + 1);  // may be negative: the vector is padded, the matrix address holds some finite number
+    const kl_lds* mp = Mst + idx * KL_LD + k0;
+    const kl_lds* bp = b + k0;
+    double mv[P::CH], bv[P::CH];
 #pragma unroll
-    for (int q = 0; q < KS_CH / 2; ++q)
-        if (2 * q < NK) mc[0][q] = *(const kl_lds2*)(row + 2 * q), bc[0][q] = *(const kl_lds2*)(b + 2 * q);
+    for (int j = 0; j < P::CH; ++j) mv[j] = mp[j], bv[j] = bp[j];
+    double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-    for (int ch = 0; ch * KS_CH < NK; ++ch) {
-        const int kn = (ch + 1) * KS_CH;
-#pragma unroll
-        for (int q = 0; q < KS_CH / 2; ++q)
-            if (kn + 2 * q < NK) mc[(ch + 1) & 1][q] = *(const kl_lds2*)(row + kn + 2 * q), bc[(ch + 1) & 1][q] = *(const kl_lds2*)(b + kn + 2 * q);
-#pragma unroll
-        for (int q = 0; q < KS_CH; q += 4) {
-            const int k = ch * KS_CH + q;
-            if (k < NK) s0 += mc[ch & 1][q / 2][0] * bc[ch & 1][q / 2][0];
-            if (k + 1 < NK) s1 += mc[ch & 1][q / 2][1] * bc[ch & 1][q / 2][1];
-            if (k + 2 < NK) s2 += mc[ch & 1][q / 2 + 1][0] * bc[ch & 1][q / 2 + 1][0];
-            if (k + 3 < NK) s3 += mc[ch & 1][q / 2 + 1][1] * bc[ch & 1][q / 2 + 1][1];
-        }
+    for (int j = 0; j < P::CH; ++j) {
+        if (j % 3 == 0) s0 += mv[j] * bv[j];
+        if (j % 3 == 1) s1 += mv[j] * bv[j];
+        if (j % 3 == 2) s2 += mv[j] * bv[j];
     }
-    return (s0 + s1) + (s2 + s3);
+    psum[lane] = (s0 + s1) + s2;
+    kl_sync();
+    const int rr = lane < NK ? lane : 0;
+    double r = psum[rr];
+    if (P::N1 > 0) r += rr < P::N1 ? psum[P::N0 + rr] : 0.0;
+    if (P::N2 > 0) r += rr < P::N2 ? psum[P::N0 + P::N1 + rr] : 0.0;
+    return r;
 }
 
 template <int NK>
 struct KsLayout {  // doubles
     static constexpr int SM = NK * KL_LD, SCH = SM + KL_I, STG = 2 * SCH;  // a stage: left chain (M, 1/d), right chain (M, 1/d)
-    static constexpr int VECS = 6 * KL_I;                                  // per chain: A (r' / w), Z (z / u), V (v / x of the block just done)
+    static constexpr int LEAD = 16;  // zeros in front of the first stage buffer (a row piece may start a few entries before its block)
+    // per chain: A (r' / w), Z (z / u), V (v / x of the block just done), each with zero padding either side, and the pieces' scratch
+    static constexpr int VECS = 6 * KS_VLEN + 2 * 64;
 };
 
 template <int NK, int ROLE>
@@ -1380,8 +1393,9 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
     const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
+    lds += KS::LEAD;                                   // (zero-filled with the stage buffers below)
     double* vec = lds + QP_STAGE_BUFS * STG;           // nj*NK: rhs -> z -> x
-    double* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KL_I]
+    double* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KS_VLEN], then [2 chains][64] partial sums
     {  // rhs -> LDS: every thread's loads first, then its stores (one trip to memory instead of one per round; see apply_F)
         constexpr int RQ = 4;
         for (int i0 = tid; i0 < nj * NK; i0 += RQ * QP_THREADS) {
@@ -1421,7 +1435,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             }
         }
     }
-    for (int i = tid; i < QP_STAGE_BUFS * STG; i += QP_THREADS) lds[i] = 0.0;
+    for (int i = tid; i < KS::LEAD + QP_STAGE_BUFS * STG; i += QP_THREADS) (lds - KS::LEAD)[i] = 0.0;
     __syncthreads();
     auto stage = [&](int s, double* buf) {
         const int jl = left_j(s), jr = right_j(s);
@@ -1446,7 +1460,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int wave = ROLE == 0 ? (tid >> 6) & 1 : 2, r = tid & 63;  // (role 1 only needs "wave >= 2")
     const bool act = r < NK;
     const int rr = act ? r : 0, g3 = 3 * (rr / 3), r3 = rr % 3;
-    const int rs = act ? r : KL_I - 1;  // lanes >= NK write the padding slot of the small vectors
+    const int rs = act ? r : NK + 12;  // lanes >= NK write a slot behind the zero padding of the chain vectors
     if (wave < 2) __builtin_amdgcn_s_setprio(QP_CHAIN_PRIO);  // see twisted_factor
     // the three coupling coefficients a chain step starts with (forward: row rr of T_{j,jp}; backward: column rr of T_{jn,j}) come from
     // global memory: fetched ONE STEP AHEAD (the trip to the L2, ~1 us under load, was the first thing every step waited for)
@@ -1488,7 +1502,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         } else if (s == SF) {
             if (wave == 0) {  // middle block: forward with both neighbours' v, then backward; x_mid goes to both chains' V
                 const kl_lds* Mst = (const kl_lds*)buf;
-                kl_lds *A0 = (kl_lds*)small, *Z0 = A0 + KL_I, *V0 = A0 + 2 * KL_I, *V1 = A0 + 5 * KL_I;
+                kl_lds *A0 = (kl_lds*)small + KS_VPAD, *Z0 = A0 + KS_VLEN, *V0 = A0 + 2 * KS_VLEN, *V1 = A0 + 5 * KS_VLEN;
+                kl_lds* ps = (kl_lds*)small + 6 * KS_VLEN;
                 double v = vec[mid * NK + rr];
                 if (mid > 0) {
                     double e0, e1, e2;
@@ -1502,10 +1517,10 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                 }
                 A0[rs] = v;
                 kl_sync();
-                const double z = Mst[SM + rr] * kl_matvec_cols<NK>(Mst, A0, rr);
+                const double z = Mst[SM + rr] * kl_matvec_cols<NK>(Mst, A0, ps, r);
                 Z0[rs] = z;
                 kl_sync();
-                const double x = kl_matvec_rows<NK>(Mst, Z0, rr);
+                const double x = kl_matvec_rows<NK>(Mst, Z0, ps, r);
                 kl_sync();
                 V0[rs] = x, V1[rs] = x;
                 if (act) vec[mid * NK + r] = x;
@@ -1516,7 +1531,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (jb >= 0) {
                 const int dir = wave == 0 ? +1 : -1;  // direction of this chain's elimination
                 const kl_lds* Mst = (const kl_lds*)(buf + (wave == 0 ? 0 : SCH));
-                kl_lds *A = (kl_lds*)small + (wave == 0 ? 0 : 3 * KL_I), *Z = A + KL_I, *V = A + 2 * KL_I;
+                kl_lds *A = (kl_lds*)small + KS_VPAD + (wave == 0 ? 0 : 3 * KS_VLEN), *Z = A + KS_VLEN, *V = A + 2 * KS_VLEN;
+                kl_lds* ps = (kl_lds*)small + 6 * KS_VLEN + (wave == 0 ? 0 : 64);
                 const double dinv = Mst[SM + rr];
                 if (fwd) {
                     double v = vec[jb * NK + rr];
@@ -1525,11 +1541,11 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                     kl_sync();
                     A[rs] = v;
                     kl_sync();
-                    const double z = dinv * kl_matvec_cols<NK>(Mst, A, rr);
+                    const double z = dinv * kl_matvec_cols<NK>(Mst, A, ps, r);
                     Z[rs] = z;
                     if (act) vec[jb * NK + r] = z;
                     kl_sync();
-                    const double vj = kl_matvec_rows<NK>(Mst, Z, rr);
+                    const double vj = kl_matvec_rows<NK>(Mst, Z, ps, r);
                     kl_sync();
                     V[rs] = vj;
                 } else {
@@ -1538,10 +1554,10 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
                     kl_sync();
                     A[rs] = wv;
                     kl_sync();
-                    const double u = vec[jb * NK + rr] - dinv * kl_matvec_cols<NK>(Mst, A, rr);
+                    const double u = vec[jb * NK + rr] - dinv * kl_matvec_cols<NK>(Mst, A, ps, r);
                     Z[rs] = u;
                     kl_sync();
-                    const double x = kl_matvec_rows<NK>(Mst, Z, rr);
+                    const double x = kl_matvec_rows<NK>(Mst, Z, ps, r);
                     kl_sync();
                     V[rs] = x;
                     if (act) vec[jb * NK + r] = x;
@@ -2851,7 +2867,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
         const int nkw = std::min(nk, 36);
         size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
         lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
-        lds = std::max(lds, sizeof(double) * ((size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KL_I + 64));  // solve_staged
+        lds = std::max(lds, sizeof(double) * (16 + (size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KS_VLEN + 2 * 64 + 64));  // solve_staged
         // chain areas + assembly progress counters (+ the assembling waves' LDS scratch in the 512-thread build)
         lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + ASM_HELPERS * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
         if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
