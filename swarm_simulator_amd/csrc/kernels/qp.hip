@@ -883,7 +883,10 @@ __device__ void assemble_needed_halves(const AsmArgs& A, int nj) {
 #define ASML_DOUBLES(nk, nb) ((nk) * KL_LD + (nb) * 36 + 3 * (nb) * ((nb) - 1) + 3 * (nb) * ((nb) - 1) + 8)
 // One wave, a sequence of knots: next() returns the next knot (0-based) or -1, done(j) is called when T_j is on its way to global memory.
 // scratch: ASML_DOUBLES(nk, nb) doubles of LDS of the wave's own.
-template <class NextFn, class DoneFn>
+// TO_GLOBAL = false: the block stays in the wave's scratch as a full symmetric image (rows KL_LD apart) for a reader in the same
+// workgroup -- the 512-thread build's chains, see twisted_factor -- and next() must not return before that reader is done with the
+// previous image.
+template <bool TO_GLOBAL, class NextFn, class DoneFn>
 __device__ __forceinline__ void assemble_knots_lds(const AsmArgs& A, double* scratch, NextFn next, DoneFn done) {
     const int nb = A.nb, oq = A.oq, nk = 9 * nb, npb = nb * (nb - 1) / 2, n3 = 3 * nb, per = n3 * (n3 + 1) / 2;
     const int lane = threadIdx.x & 63;
@@ -951,19 +954,21 @@ __device__ __forceinline__ void assemble_knots_lds(const AsmArgs& A, double* scr
             }
         }
         kl_sync();
-        double* Tg = A.Td + (size_t)j * nk * nk;
-        if ((nk & 1) == 0) {
-            // (the factorisation uses the entries (r, k >= r) only: knot_ldl.  Row and column of a lane's pair advance by 128 elements
-            // per round: carried along, not divided out -- nk is not a compile-time constant here, and two integer divisions per pair
-            // were more instructions than everything else in this loop)
-            int r = row0, k2 = col0;
-            for (int idx = lane; idx < nk * nk / 2; idx += 64) {
-                if (QP_T_WRITE_FULL || k2 + 1 >= r) *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
-                r += drow, k2 += dcol;
-                if (k2 >= nk) k2 -= nk, r++;
+        if (TO_GLOBAL) {
+            double* Tg = A.Td + (size_t)j * nk * nk;
+            if ((nk & 1) == 0) {
+                // (the factorisation uses the entries (r, k >= r) only: knot_ldl.  Row and column of a lane's pair advance by 128 elements
+                // per round: carried along, not divided out -- nk is not a compile-time constant here, and two integer divisions per pair
+                // were more instructions than everything else in this loop)
+                int r = row0, k2 = col0;
+                for (int idx = lane; idx < nk * nk / 2; idx += 64) {
+                    if (QP_T_WRITE_FULL || k2 + 1 >= r) *(kl_d2*)(Tg + 2 * idx) = *(const kl_lds2*)(Timg + r * KL_LD + k2);
+                    r += drow, k2 += dcol;
+                    if (k2 >= nk) k2 -= nk, r++;
+                }
+            } else {
+                for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
             }
-        } else {
-            for (int idx = lane; idx < nk * nk; idx += 64) Tg[idx] = Timg[(idx / nk) * KL_LD + idx % nk];
         }
         done(j);
         kl_sync();
@@ -973,7 +978,7 @@ __device__ __forceinline__ void assemble_knots_lds(const AsmArgs& A, double* scr
 __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
     const int wave = threadIdx.x >> 6, NW = QP_THREADS / 64;
     int j = wave - NW;
-    assemble_knots_lds(A, lds + (size_t)wave * ASML_DOUBLES(9 * A.nb, A.nb), [&] { j += NW; return j < nj ? j : -1; }, [](int) {});
+    assemble_knots_lds<true>(A, lds + (size_t)wave * ASML_DOUBLES(9 * A.nb, A.nb), [&] { j += NW; return j < nj ? j : -1; }, [](int) {});
 }
 
 __device__ inline AsmArgs asm_args(const RowCtx& c) {
@@ -1079,22 +1084,33 @@ __device__ __forceinline__ void coupling_coef(const QpWs& w, int j, int dir, int
     e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
 }
 
-// the diagonal block of one knot: S = T_j (- U) into registers, factorised (column images in C, 1 / d in I); P / pbase: see kl_ldl
+// the diagonal block of one knot: S = T_j (- U) into registers, factorised (column images in C, 1 / d in I); P / pbase: see kl_ldl.
+// Timg != nullptr (512-thread build): T_j is read from the assembling wave's LDS image instead of global memory -- the block never leaves
+// the CU, and the chain does not start every knot with a trip to memory --; when the values have arrived *consumed = consumed_value
+// tells the assembling wave that it may overwrite the image.
 template <int NK>
-__device__ __forceinline__ bool knot_ldl(const QpWs& w, int j, bool minus_u, kl_lds* base, int r, bool act, int rr, kl_ldsi* P, int pbase) {
+__device__ __forceinline__ bool knot_ldl(const QpWs& w, int j, bool minus_u, kl_lds* base, int r, bool act, int rr, kl_ldsi* P, int pbase,
+                                         const kl_lds* Timg = nullptr, kl_ldsi* consumed = nullptr, int consumed_value = 0) {
     using A = KlArea<NK>;
     kl_lds *C = base + A::C, *I = base + A::I, *U = base + A::C;
     double a[NK];
-    const double* Tg = w.Td + (size_t)j * NK * NK;
-    // T is symmetric: column access = row access; only k <= r was assembled and is used.  Not fetching the unused half (the lanes r < k
-    // re-reading the diagonal entry of row k: -DQP_T_HALF_ROWS) saves 2.6 % of the kernel's HBM-side bytes and COSTS 2.7 % of its time (A/B on
-    // one box, 85.6 k vs 87.9 k agent-trajectories/s): whole rows it is.
+    if (Timg) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a[k] = Timg[k * KL_LD + rr];
+        kl_sync();
+        if (consumed) kl_publish(consumed, consumed_value);
+    } else {
+        const double* Tg = w.Td + (size_t)j * NK * NK;
+        // T is symmetric: column access = row access; only k <= r was assembled and is used.  Not fetching the unused half (the lanes r < k
+        // re-reading the diagonal entry of row k: -DQP_T_HALF_ROWS) saves 2.6 % of the kernel's HBM-side bytes and COSTS 2.7 % of its time (A/B on
+        // one box, 85.6 k vs 87.9 k agent-trajectories/s): whole rows it is.
 #pragma unroll
 #ifdef QP_T_HALF_ROWS
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + (rr > k ? rr : k)];
+        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + (rr > k ? rr : k)];
 #else
-    for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
+        for (int k = 0; k < NK; ++k) a[k] = Tg[k * NK + rr];
 #endif
+    }
     if (minus_u) {
 #pragma unroll
         for (int k = 0; k < NK; ++k) a[k] -= U[rr * KL_LDU + k];
@@ -1153,6 +1169,9 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
 // progress words of chain h (LDS ints behind the assembly counters): [2h] = images / pivots published by the chain wave (monotone over
 // the whole factorisation: block i publishes i * (NK + 1) + 1 ...), [2h + 1] = blocks whose M rows the companion wave has put into MX
 #define CHAIN_SYNC(cnt, h) ((kl_ldsi*)((cnt) + 64 + 2 * (h)))
+// 512-thread build: [h] = number of blocks chain h has read out of the assembling waves' LDS images (a wave may overwrite its image of
+// step i - 2 when this says i - 1)
+#define ASM_CONSUMED(cnt, h) ((kl_ldsi*)((cnt) + 72 + (h)))
 
 // one chain: blocks j0, j0+dir, ... (count of them).  The chain wave factorises; its companion wave (wave_factor_follow) computes
 // M_j = L_j^-T a column or two behind and stores it.  On return the chain's LDS area holds the coupling factor X towards the middle
@@ -1176,7 +1195,9 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
         CHAIN_T(26);
         double e0, e1, e2, x[NK];
         coupling_coef(w, j, dir, rr, e0, e1, e2);  // (issued here: three loads from the L2, ~1 us under load, needed after the factorisation)
-        if (!knot_ldl<NK>(w, j, i > 0, base, r, act, rr, P, i * (NK + 1))) ok = false;
+        // (512-thread build: T_j from the LDS image of the assembling wave (side h, parity of the step), see twisted_factor)
+        const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsW - (size_t)h * A::SIZE + 2 * A::SIZE + 128 + (size_t)(h + 2 * (i & 1)) * ASML_DOUBLES(NK, (NK / 9))) : nullptr;
+        if (!knot_ldl<NK>(w, j, i > 0, base, r, act, rr, P, i * (NK + 1), Timg, ASM_CONSUMED(cnt, h), i + 1)) ok = false;
         kl_await(Mdone, i + 1, seen);
         kl_coupling_rows<NK>(x, MX, r, act, e0, e1, e2);
         CHAIN_T(27);
@@ -1201,7 +1222,8 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     // 122.4 -> 121.1 ms.  With two workgroups per CU the polling companion costs the neighbour more than it saves (-1.3 % at 2000
     // resident, A/B on one box): the 256-thread build keeps M on the chain wave.
     kl_ldsi* scratch = CHAIN_SYNC(cnt, 2);
-    const bool ok = knot_ldl<NK>(w, mid, nsy > 0, bl, r, act, rr, scratch, 0);
+    const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsL + 2 * A::SIZE + 128 + (size_t)(2 * (cnt_idx & 1)) * ASML_DOUBLES(NK, (NK / 9))) : nullptr;
+    const bool ok = knot_ldl<NK>(w, mid, nsy > 0, bl, r, act, rr, scratch, 0, Timg);
     if (!QP_MID_FOLLOW) {
         int seen = 0;
         knot_inverse<NK, false>(w, mid, bl, r, act, scratch, 0, seen, scratch, 0);
@@ -1245,14 +1267,17 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
         const int hw = (threadIdx.x >> 6) - ASM_WAVE0, side = hw & 1, par = hw >> 1;  // par: parity of the steps this wave serves
         double* scratch = lds + 2 * AREA + 128 + (size_t)hw * ASML_DOUBLES(NK, (NK / 9));
         int i = par - 2;
-        assemble_knots_lds(
+        kl_ldsi* consumed = ASM_CONSUMED(cnt, side);
+        int seen_c = 0;
+        assemble_knots_lds<false>(
             A, scratch,
             [&] {
                 for (i += 2; i <= SF; i += 2) {
-                    if (i < SF) {
-                        if (side ? i < nr : i < nl) return side ? d.nj - 1 - i : i;
-                    } else if (side == 0)
-                        return mid;
+                    const bool work = i < SF ? (side ? i < nr : i < nl) : side == 0;
+                    if (work) {
+                        if (i >= 2) kl_await(consumed, i - 1, seen_c);  // the chain has read this wave's image of step i - 2
+                        return i < SF ? (side ? d.nj - 1 - i : i) : mid;
+                    }
                     // nothing to assemble for this wave at step i: announce it all the same
                     if ((threadIdx.x & 63) == 0)
                         __hip_atomic_fetch_add(cnt + i, i < SF ? ASM_HELPERS / 2 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
