@@ -9,7 +9,7 @@ p = Param.test_sweep()
 for mf in sys.argv[1:]:
     m = host.load_mission(mf)
     worlds, plans = [], []
-    for i in range(1, 51, 3):
+    for i in range(1, 51, int(os.environ.get("ROB_STEP", "3"))):  # every third map by default (17 maps)
         w = host.load_world(f"map{i}.bt", p)
         try:
             pr = host.ecbs_plan(w, m, p)
