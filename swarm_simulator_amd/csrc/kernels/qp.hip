@@ -265,13 +265,27 @@ __constant__ double c_basis[36] = {-1, 5,   -10, 10, -5, 1, 5,  -20, 30, -20, 5,
 __device__ inline size_t pair_index(int N, int qi, int qj) { return (size_t)qi * N - (size_t)qi * (qi + 1) / 2 + (qj - qi - 1); }
 
 // ---- block reductions ------------------------------------------------------------------------------------------
+// Inside a wave by DPP (quad permutes, half-row and row mirrors) and four readlanes -- six butterfly steps of ds_bpermute pairs are
+// ~1000 cycles of dependent LDS round trips, and an interior-point iteration has ten of these reductions --, across the waves through
+// `red`.  Two barriers: the one in front of the write would only protect the previous reduction's readers, which the barrier at ITS
+// end has already let go.
+template <int CTRL>
+__device__ __forceinline__ double qp_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qp_red_op(double a, double b, int op) { return op == 0 ? a + b : (op == 1 ? fmax(a, b) : fmin(a, b)); }
+__device__ __forceinline__ double qp_rl(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ inline double block_reduce(double v, int op /*0 sum,1 max,2 min*/, double* red) {
-    for (int o = 32; o > 0; o >>= 1) {
-        double t = __shfl_xor(v, o);
-        v = op == 0 ? v + t : (op == 1 ? fmax(v, t) : fmin(v, t));
-    }
+    v = qp_red_op(v, qp_dpp_f64<0xB1>(v), op);   // quad_perm [1,0,3,2]
+    v = qp_red_op(v, qp_dpp_f64<0x4E>(v), op);   // quad_perm [2,3,0,1]
+    v = qp_red_op(v, qp_dpp_f64<0x141>(v), op);  // row_half_mirror
+    v = qp_red_op(v, qp_dpp_f64<0x140>(v), op);  // row_mirror: every lane of a row holds the row's result
+    v = qp_red_op(qp_red_op(qp_rl(v, 0), qp_rl(v, 16), op), qp_red_op(qp_rl(v, 32), qp_rl(v, 48), op), op);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double r = red[0];
