@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../kernels/jqp.h"
 #include "../kernels/rbp_dev.h"
 
 namespace {
@@ -79,6 +80,8 @@ struct rbp_session {
     std::vector<float> rsfc_normal0;
     bool have_corridor_inputs = false;
     bool planner_ok = true;   // false: the batch is wider than the QP kernel supports (corridor-only session)
+    bool joint_wide = false;  // the joint QP (plan/sequential = false) runs on the grid-wide solver (kernels/jqp.hip)
+    JointStats joint_stats{};
     int last_stages = 0;      // stages of the last rbp_session_run (time_scale only concerns a run that included the planner)
 };
 
@@ -165,7 +168,17 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     // a batch wider than the QP kernel factorises (the joint QP of a mission with more than planner_max_batch() agents) only
     // concerns the PLANNER stage: such a session can still run the corridor (rbp_corridor_update*, the sharded corridor); the
     // planner stage is refused in rbp_session_run and no QP workspace is reserved
-    const bool planner_ok = !(biter > 0 && bs > planner_max_batch());
+    // ... and so does a mission with more than QP_MAX_M segments: the factor chains' LDS progress words sit behind 64 per-step
+    // assembly counters (twisted_factor in kernels/qp.hip), one per step of the longer half chain, i.e. M - 1 <= 127 knots
+    // The joint QP of a mission (plan/sequential = false: one batch of all N agents) is spread over the whole chip by kernels/jqp.hip
+    // when it is wide enough to pay for a launch per phase (default: more than 32 agents, i.e. knot blocks of order > 288; RBP_JOINT_WIDE
+    // = 0 / 1 forces the one-workgroup / the grid-wide solver).  It has no limit on N.
+    bool joint_wide = false;
+    if (!param->sequential && biter > 0 && N >= 2) {
+        const char* e = getenv("RBP_JOINT_WIDE");
+        joint_wide = e ? e[0] == '1' : N > 32;
+    }
+    const bool planner_ok = joint_wide || (!(biter > 0 && bs > planner_max_batch()) && M <= QP_MAX_M);
 
     struct Guard {  // every error path below releases the session (and with it the arena)
         rbp_session* s;
@@ -180,7 +193,10 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     for (int k = 0; k < K; ++k) s->Mk[k] = plans[k].M, s->MBk[k] = plans[k].max_boxes;
     const int P = M + 1, npair = N * (N - 1) / 2, oq = 6 * M;
     s->planner_ok = planner_ok;
-    s->qp_ws_per_mission = planner_ok ? std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs)) : 0;
+    s->joint_wide = joint_wide;
+    s->qp_ws_per_mission = !planner_ok ? 0
+                           : joint_wide ? joint_workspace_bytes(N, M)
+                                        : std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs));
     {
         hipDeviceProp_t prop;
         s->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -391,11 +407,21 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
     if ((stages & RBP_STAGE_PLANNER) && !s->planner_ok)
-        return fail(RBP_ERR_BAD_ARGUMENT, "batch wider than " + std::to_string(planner_max_batch()) +
-                                              " agents (joint QP of a large mission) is not supported by the QP kernel");
+        return fail(RBP_ERR_BAD_ARGUMENT, s->d.M > QP_MAX_M
+                                              ? "more than " + std::to_string(QP_MAX_M) + " segments per mission are not supported by the QP kernel"
+                                              : "batch wider than " + std::to_string(planner_max_batch()) +
+                                                    " agents (joint QP of a large mission) is not supported by the QP kernel");
     s->last_stages = stages;
     if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
-    if (stages & RBP_STAGE_PLANNER) {
+    if ((stages & RBP_STAGE_PLANNER) && s->joint_wide) {
+        // grid-wide joint QP: a launch per phase; the host learns once per interior-point iteration whether any mission is still
+        // running, so this call SYNCHRONISES the stream (unlike the batch path, which only enqueues)
+        launch_planner_prologue(s->d, st);
+        int rc = RBP_OK;
+        if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats);
+        if (rc) return fail(rc, "joint QP: HIP error");
+        launch_planner_epilogue(s->d, st);
+    } else if (stages & RBP_STAGE_PLANNER) {
         // two workgroups per CU (the 128-VGPR build) pay off as soon as there are more missions than CUs: the 256-VGPR build
         // would need a second round (measured at 300/400/500 missions: +17-21 %)
         const char* force = getenv("RBP_QP_VARIANT");  // developer override: "w2" | "w4"

@@ -1,0 +1,32 @@
+// jqp.h — the grid-wide joint QP (kernels/jqp.hip): workspace layout and launcher.
+#pragma once
+#include "rbp_dev.h"
+
+#define JQ_PC 16  // partner agents per sweep thread (a control point's pair rows are split into ceil(N / JQ_PC) chunks)
+
+// offsets (in doubles) of one mission's workspace; the same for every mission of a session (sized for the session's largest M)
+struct JLayout {
+    int N, MS, nkpS, nblkS, njS, nch, nred;
+    size_t stride, zero_doubles;
+    size_t o_state, o_segsc, o_Lk, o_Dk, o_Ek, o_boxlo, o_boxhi, o_dxa, o_dx, o_rbase, o_rhs, o_wv, o_red;
+    size_t o_bs[2], o_bz[2], o_ps[2], o_pz[2], o_pwgt, o_acc, o_Y, o_P, o_scr, o_inv;
+    size_t o_pol;  // polish workspace (jqp_polish.inc)
+};
+
+struct JArgs {
+    DevSession S;
+    double* ws;
+    JLayout L;
+};
+
+struct JointStats {
+    int rounds;         // interior-point rounds enqueued (= host synchronisations)
+    int polish_rounds;  // active-set rounds of the polish
+};
+
+JLayout jq_layout(int N, int MS);
+size_t joint_workspace_bytes(int N, int MS);
+// dummy_kernel .. timescale_kernel around it are launched by the caller (launch_planner_prologue / _epilogue in qp.hip)
+int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats);
+void launch_planner_prologue(const DevSession& s, hipStream_t st);
+void launch_planner_epilogue(const DevSession& s, hipStream_t st);

@@ -1,0 +1,1227 @@
+// jqp.hip — the JOINT RBP QP (plan/sequential = false, the reference's code default: param.hpp:67, setBatch rbp_planner.hpp:857-859
+// "batch_size = N, batch_iter = 1") spread over the whole chip: one QP over all N agents of a mission, solved by MANY workgroups.
+//
+// kernels/qp.hip runs a batch QP on ONE workgroup; that is the right shape for the reference's sequential schedule (batches of 4..8
+// agents, thousands of missions in flight) and the wrong one for the joint QP, whose Newton matrix has knot blocks of order
+// nk = 9 N (576 for 64 agents, 2304 for 256).  Same mathematics here (null-space coordinates u_j per knot, Mehrotra predictor-
+// corrector with the wide-neighbourhood step rule and the 1e-9 dual regularisation, see qp.hip), different machine mapping:
+//
+//   * a LAUNCH PER PHASE instead of a barrier per phase: every phase of an interior-point iteration is a kernel over all missions
+//     of the session (grid.y / grid.z = mission), the kernel boundary is the grid-wide barrier (~1.5 us), and the per-mission scalars
+//     (mu, sigma, alpha, state) live in a small device record written by one-workgroup "control" kernels -- the host only polls
+//     "is any mission still running" once per iteration;
+//   * ROW SWEEPS over the whole chip: a thread owns one control point of one agent and a CHUNK of 16 partner agents (N / 16 chunks
+//     per control point give N * ceil(N / 16) workgroups per mission); a pair row is computed by both its agents from the single
+//     stored (s, z) -- bit-identical arithmetic in canonical orientation -- and written back by the lower agent only; the partial
+//     3x3 accumulators of the chunks are summed in a fixed order by their consumers (no floating-point atomics: bit-reproducible);
+//   * the BLOCK-TRIDIAGONAL FACTORISATION keeps explicit inverses of the knots' Schur complements, S_j^-1, computed by a BLOCKED
+//     SYMMETRIC SWEEP (Gauss-Jordan without pivoting on an SPD matrix) in 64 x 64 tiles on v_mfma_f64_16x16x4_f64:  step k inverts
+//     the pivot tile, forms the panel Y_I = B_Ik P (one launch), and applies the rank-64 update B_IJ -= Y_I B_Jk' to every tile of
+//     the lower triangle (one launch) -- uniform parallelism (nblk (nblk + 1) / 2 tiles) in every step, no triangular solves, one
+//     kernel boundary per dependent step, nk^3 flops per knot (the same as Cholesky + triangular inverse).  The pivot tile of step
+//     k + 1 is inverted by the workgroup that has just updated it (look-ahead: off the other tiles' path).  Because the coupling
+//     blocks T_{j+1,j} are 3x3-block diagonal, the Schur update T_{j+1} - C S_j^-1 C' is an O(nk^2) elementwise pass fused with the
+//     assembly of T_{j+1} from the sweeps' accumulators (T_j is never stored).  The elimination is TWISTED (both ends towards the
+//     middle knot): half the dependent depth, the two chains share every launch;
+//   * SUBSTITUTIONS are matrix-vector products with the stored inverses (16-row slabs, one launch per knot step and direction).
+//
+// Layout: knot matrices are TILE-MAJOR (64 x 64 tiles of 32 KB, row-major inside), order nkp = nk rounded up to 64 (identity
+// padding).  During the sweep only tiles I >= J are valid; the last step writes S_j^-1 with both triangles.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "jqp.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int JT = 64;          // tile order
+constexpr int JTT = JT * JT;    // doubles per tile
+constexpr int JQ_MAX_ITERS = 80;
+constexpr double JQ_MU0 = 3e-1, JQ_SFLOOR = 1e-1, JQ_DREG = 1e-9, JQ_STEP_FRAC = 0.997, JQ_NBHD_GAMMA = 1e-3;
+
+// per-mission state record (doubles)
+enum { ST_STATE = 0 /* 0 running, 1 converged, 2 failed */, ST_ITER, ST_PAR /* which (s, z) pair is current */, ST_RETRY, ST_MU, ST_GAP, ST_PRES,
+       ST_DRES, ST_SIGMU, ST_ALPHA, ST_APPLIED, ST_BT, ST_NROWS, ST_KKT, ST_FLOPS, ST_REASON, ST_AAFF, ST_POLISHED, ST_N = 32 };
+// reduction slots (each [4 components][nred workgroups])
+enum { RS_BUILD = 0 /* sum0 = gap, vmax = pres */, RS_POST /* dmax, gmax */, RS_AFF /* vmax, sum0, sum1, sum2 */, RS_STEP /* vmax */,
+       RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_OBJ, RS_NSLOT };
+
+struct JDims {
+    int N, M, oq, nj, nk, nkp, nblk, npair, nch, ncp;
+};
+__host__ __device__ inline JDims jdims(int N, int M) {
+    JDims d;
+    d.N = N, d.M = M, d.oq = 6 * M, d.nj = M - 1, d.nk = 9 * N, d.nkp = (d.nk + JT - 1) / JT * JT, d.nblk = d.nkp / JT;
+    d.npair = N * (N - 1) / 2, d.nch = (N + JQ_PC - 1) / JQ_PC, d.ncp = N * d.oq;
+    return d;
+}
+
+__constant__ double jc_Qbase[36] = {720,  -1800, 1200,  0,     0,     -120, -1800, 4800,  -3600, 0,     600,   0,
+                                    1200, -3600, 3600,  -1200, 0,     0,    0,     0,     -1200, 3600,  -3600, 1200,
+                                    0,    600,   0,     -3600, 4800,  -1800, -120, 0,     0,     1200,  -1800, 720};
+
+__device__ inline size_t pair_index(int N, int qi, int qj) { return (size_t)qi * N - (size_t)qi * (qi + 1) / 2 + (qj - qi - 1); }
+
+// element (r, c) of a tile-major matrix with nblk tile columns
+__device__ __forceinline__ size_t telem(int nblk, int r, int c) { return ((size_t)(r >> 6) * nblk + (c >> 6)) * JTT + (size_t)(r & 63) * JT + (c & 63); }
+
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// ---- deterministic block reduction (256 threads): op 0 sum, 1 max, 2 min ------------------------------------------------
+__device__ __forceinline__ double red_op(double a, double b, int op) { return op == 0 ? a + b : (op == 1 ? fmax(a, b) : fmin(a, b)); }
+__device__ inline double block_reduce(double v, int op, double* red /* >= 4 doubles of LDS */) {
+    for (int o = 32; o > 0; o >>= 1) v = red_op(v, __shfl_xor(v, o), op);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = red_op(r, red[i], op);
+    return r;
+}
+
+struct Ws {  // pointers into one mission's workspace
+    double *st, *segsc, *Lk, *Dk, *Ek, *boxlo, *boxhi;
+    double *bs[2], *bz[2], *ps[2], *pz[2], *pwgt, *acc, *dxa, *dx, *rbase, *rhs, *wv, *red, *Y, *P, *scr, *inv;
+};
+__device__ __forceinline__ Ws carve(const JArgs& A, int mission) {
+    double* b = A.ws + (size_t)mission * A.L.stride;
+    const JLayout& L = A.L;
+    Ws w;
+    w.st = b + L.o_state, w.segsc = b + L.o_segsc, w.Lk = b + L.o_Lk, w.Dk = b + L.o_Dk, w.Ek = b + L.o_Ek;
+    w.boxlo = b + L.o_boxlo, w.boxhi = b + L.o_boxhi;
+    for (int p = 0; p < 2; ++p) w.bs[p] = b + L.o_bs[p], w.bz[p] = b + L.o_bz[p], w.ps[p] = b + L.o_ps[p], w.pz[p] = b + L.o_pz[p];
+    w.pwgt = b + L.o_pwgt, w.acc = b + L.o_acc, w.dxa = b + L.o_dxa, w.dx = b + L.o_dx, w.rbase = b + L.o_rbase, w.rhs = b + L.o_rhs;
+    w.wv = b + L.o_wv, w.red = b + L.o_red, w.Y = b + L.o_Y, w.P = b + L.o_P, w.scr = b + L.o_scr, w.inv = b + L.o_inv;
+    return w;
+}
+__device__ __forceinline__ double* red_slot(const Ws& w, const JLayout& L, int slot, int comp) { return w.red + ((size_t)slot * 4 + comp) * L.nred; }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// setup: mission constants (qp.hip mission_constants), SFC box per (agent, segment) (rbp_planner.hpp:447-453), pinned end control
+// points (rows 0-5 of Aeq_base, :380-387), state record.  One workgroup per mission.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jq_setup(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.x, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const JDims d = jdims(N, M);
+    const double* T = S.T + (size_t)mission * (MS + 1);
+    if (tid == 0) {
+        for (int i = 0; i < ST_N; ++i) w.st[i] = 0.0;
+        w.st[ST_STATE] = S.status[mission] != 0 ? 2.0 : 0.0;
+        w.st[ST_NROWS] = (double)((size_t)(d.oq - 6) * (6 * (size_t)N + d.npair));
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += 256) w.segsc[m] = pow(T[m + 1] - T[m], -5.0);
+    for (int j = tid; j <= M; j += 256) {
+        double* L = w.Lk + 9 * j;
+        for (int e = 0; e < 9; ++e) L[e] = 0;
+        if (j >= 1 && j < M) {
+            const double r = (T[j] - T[j - 1]) / (T[j + 1] - T[j]);
+            L[0] = (1 + r) * (1 + r), L[1] = -2 * r * (1 + r), L[2] = r * r;
+            L[3] = 1 + r, L[4] = -r, L[5] = 0;
+            L[6] = 1, L[7] = 0, L[8] = 0;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j <= M; j += 256) {
+        double* D = w.Dk + 9 * j;
+        double* E = w.Ek + 9 * j;
+        for (int e = 0; e < 9; ++e) D[e] = 0, E[e] = 0;
+        if (j >= 1 && j < M) {
+            const double sl = pow(T[j] - T[j - 1], -5.0), sr = pow(T[j + 1] - T[j], -5.0);
+            const double* L = w.Lk + 9 * j;
+            double QL[9];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double s = 0;
+                    for (int c = 0; c < 3; ++c) s += jc_Qbase[6 * (3 + a) + 3 + c] * sl * L[3 * c + b];
+                    QL[3 * a + b] = s;
+                }
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double s = 0;
+                    for (int c = 0; c < 3; ++c) s += L[3 * c + a] * QL[3 * c + b];
+                    D[3 * a + b] = 2 * (s + jc_Qbase[6 * a + b] * sr);
+                }
+            if (j + 1 < M) {
+                const double* Ln = w.Lk + 9 * (j + 1);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        double s = 0;
+                        for (int c = 0; c < 3; ++c) s += jc_Qbase[6 * a + 3 + c] * sr * Ln[3 * c + b];
+                        E[3 * a + b] = 2 * s;
+                    }
+            }
+        }
+    }
+    // SFC box of every (agent, segment): first box with end time >= T[m+1]
+    for (int a = tid; a < N; a += 256) {
+        int nbx = S.sfc_count[(size_t)mission * N + a];
+        if (nbx <= 0) {
+            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_BAD_ARGUMENT);
+            w.st[ST_STATE] = 2.0;
+            nbx = 1;
+        }
+        const double* bt = S.sfc_time + ((size_t)mission * N + a) * S.max_boxes;
+        int bi = 0;
+        for (int m = 0; m < M; ++m) {
+            while (bi < nbx && bt[bi] < T[m + 1]) bi++;
+            const int sel = bi < nbx ? bi : nbx - 1;
+            const double* bx = S.sfc_box + (((size_t)mission * N + a) * S.max_boxes + sel) * 6;
+            for (int k = 0; k < 3; ++k) w.boxlo[((size_t)a * M + m) * 3 + k] = bx[k], w.boxhi[((size_t)a * M + m) * 3 + k] = bx[3 + k];
+        }
+    }
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    for (int it = tid; it < N * 3; it += 256) {
+        const int a = it / 3, k = it % 3;
+        const double* stt = S.start + ((size_t)mission * N + a) * 9;
+        const double* gl = S.goal + ((size_t)mission * N + a) * 9;
+        const double h0 = T[1] - T[0], hT = T[M] - T[M - 1];
+        double* x = ctrl + ((size_t)a * 3 + k) * d.oq;
+        x[0] = stt[k], x[1] = x[0] + h0 * stt[k + 3] / 5, x[2] = 2 * x[1] - x[0] + h0 * h0 * stt[k + 6] / 20;
+        double* xe = x + 6 * (M - 1);
+        xe[5] = gl[k], xe[4] = xe[5] - hT * gl[k + 3] / 5, xe[3] = 2 * xe[4] - xe[5] + hT * hT * gl[k + 6] / 20;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// row sweeps.  Rows (G x <= h form, as in qp.hip and the oracle):
+//   bound (a, k, side, j6):  +x <= hi / -x <= -lo                    rbp_planner.hpp:626-635
+//   pair  (lo < hi, j6):     n . x_lo - n . x_hi <= -(r_lo + r_hi)   :668-679
+// Control points j6 < 3 and j6 >= 6M - 3 are pinned: their rows are constants, checked once (PASS_INIT) against 1e-6.
+// ------------------------------------------------------------------------------------------------------------------------
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_STEP, PASS_UPBUILD, PASS_CAND, PASS_VERIFY };
+
+struct PassIO {
+    double sigma_mu, alpha;
+    double sum0, sum1, sum2, vmax, vmin;
+};
+
+// one row: see row_op in qp.hip (same arithmetic).  s, z: current state; out: new state (INIT, UPBUILD) through so / zo2.
+template <int PASS>
+__device__ __forceinline__ void row_op(double slack, double ga, double gd, double s, double z, PassIO& io, double cw, double& wgt, double& v,
+                                       double& zo, double& sn_out, double& zn_out) {
+    if (PASS == PASS_INIT) {
+        const double s0 = slack < JQ_SFLOOR ? JQ_SFLOOR : slack;
+        sn_out = s0, zn_out = JQ_MU0 / s0;
+    } else if (PASS == PASS_BUILD) {
+        const double rg = s - slack;
+        wgt = z * fast_rcp(s + JQ_DREG * z);
+        v = -wgt * (rg - s);
+        zo = z;
+        io.sum0 += cw * s * z;
+        io.vmax = fmax(io.vmax, fabs(rg));
+    } else if (PASS == PASS_AFF) {
+        const double rg = s - slack;
+        const double iz = fast_rcp(z), is = fast_rcp(s);
+        wgt = z * fast_rcp(s + JQ_DREG * z);
+        const double dza = wgt * (ga + rg - s);
+        const double dsa = -s - s * dza * iz;
+        const double cc = dsa * dza;
+        io.vmax = fmax(io.vmax, fmax(-dsa * is, -dza * iz));
+        io.sum0 += cw * s * z, io.sum1 += cw * (s * dza + z * dsa), io.sum2 += cw * cc;
+        v = -wgt * (rg - s - cc * iz);
+        wgt = wgt * iz;
+    } else if (PASS == PASS_STEP) {
+        const double rg = s - slack;
+        const double iz = fast_rcp(z), is = fast_rcp(s);
+        wgt = z * fast_rcp(s + JQ_DREG * z);
+        const double dza = wgt * (ga + rg - s);
+        const double cc = (-s - s * dza * iz) * dza;
+        const double rcc = s * z + cc - io.sigma_mu;
+        const double dz = wgt * (gd + rg - rcc * iz);
+        const double ds = -(rcc + s * dz) * iz;
+        io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
+    } else if (PASS == PASS_UPBUILD) {
+        const double rg = s - (slack + io.alpha * gd);  // the old point: slack_old = slack + alpha * gd
+        const double iz = fast_rcp(z);
+        const double w0 = z * fast_rcp(s + JQ_DREG * z);
+        const double dza = w0 * (ga + rg - s);
+        const double cc = (-s - s * dza * iz) * dza;
+        const double rcc = s * z + cc - io.sigma_mu;
+        const double dz = w0 * (gd + rg - rcc * iz);
+        const double ds = -(rcc + s * dz) * iz;
+        const double sn = s + io.alpha * ds, zn = z + io.alpha * dz;
+        sn_out = sn, zn_out = zn;
+        io.vmin = fmin(io.vmin, sn * zn);
+        const double rgn = sn - slack;
+        wgt = zn * fast_rcp(sn + JQ_DREG * zn);
+        v = -wgt * (rgn - sn);
+        zo = zn;
+        io.sum0 += cw * sn * zn;
+        io.vmax = fmax(io.vmax, fabs(rgn));
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    __shared__ double red[8];
+    if (w.st[ST_STATE] != 0.0) return;
+    if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0) return;
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const JDims d = jdims(N, M);
+    const int oq = d.oq, ncp = d.ncp;
+    const int a = blockIdx.x / d.nch, ch = blockIdx.x % d.nch;
+    const int par = (int)w.st[ST_PAR];
+    const double *bs = w.bs[par], *bz = w.bz[par], *ps = w.ps[par], *pz = w.pz[par];
+    double *bs2 = w.bs[par ^ 1], *bz2 = w.bz[par ^ 1], *ps2 = w.ps[par ^ 1], *pz2 = w.pz[par ^ 1];
+    if (PASS == PASS_INIT) bs2 = w.bs[par], bz2 = w.bz[par], ps2 = w.ps[par], pz2 = w.pz[par];
+    const double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    const float* normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
+    const double* radius = S.radius + (size_t)mission * N;
+    constexpr bool build = (PASS == PASS_BUILD || PASS == PASS_UPBUILD);
+    constexpr bool aff = (PASS == PASS_AFF);
+    constexpr bool accum = build || aff;
+    constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
+    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD);
+    constexpr bool rd_sz = PASS != PASS_INIT;
+    constexpr bool wr_sz = (PASS == PASS_INIT || PASS == PASS_UPBUILD);
+    PassIO io;
+    io.sigma_mu = w.st[ST_SIGMU], io.alpha = w.st[ST_ALPHA];
+    io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 0, io.vmin = 1e300;
+    double pin_viol = 0;
+    const double ra = radius[a];
+    const int b0 = ch * JQ_PC, b1 = min(N, b0 + JQ_PC);
+    for (int j6 = tid; j6 < oq; j6 += 256) {
+        const bool pinned = (j6 < 3 || j6 >= oq - 3);
+        if (pinned && PASS != PASS_INIT) continue;
+        const int seg = j6 / 6;
+        double xa[3], da[3], dd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            xa[k] = ctrl[((size_t)a * 3 + k) * oq + j6];
+            da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = need_dd ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+        }
+        double Sm[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
+        if (ch == 0) {  // bound rows
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double hi = w.boxhi[((size_t)a * M + seg) * 3 + k], lo = w.boxlo[((size_t)a * M + seg) * 3 + k];
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const size_t r = (size_t)(2 * k + side) * ncp + (size_t)a * oq + j6;
+                    const double sg = side == 0 ? 1.0 : -1.0;
+                    const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
+                    if (pinned) {
+                        pin_viol = fmax(pin_viol, -slack);
+                        continue;
+                    }
+                    double wgt = 0, v = 0, zo = 0, sn = 0, zn = 0;
+                    const double s = rd_sz ? bs[r] : 0.0, z = rd_sz ? bz[r] : 0.0;
+                    row_op<PASS>(slack, sg * da[k], sg * dd[k], s, z, io, 1.0, wgt, v, zo, sn, zn);
+                    if (wr_sz) bs2[r] = sn, bz2[r] = zn;
+                    if (accum) {
+                        const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);
+                        if (build) {
+                            Sm[dg] += wgt, gz[k] += sg * zo, yv[k] += sg * v;
+                        } else {
+                            Sm[k] += sg * v, Sm[3 + k] += sg * wgt;
+                        }
+                    }
+                }
+            }
+        }
+        for (int b = b0; b < b1; ++b) {
+            if (b == a) continue;
+            const bool a_lo = a < b;
+            const size_t pi = pair_index(N, a_lo ? a : b, a_lo ? b : a);
+            const size_t r = pi * oq + j6;
+            const float* nv = normals + (pi * M + seg) * 3;
+            const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
+            double xb[3], gab = 0, gdb = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xb[k] = ctrl[((size_t)b * 3 + k) * oq + j6];
+            const double e0 = a_lo ? xb[0] - xa[0] : xa[0] - xb[0], e1 = a_lo ? xb[1] - xa[1] : xa[1] - xb[1],
+                         e2 = a_lo ? xb[2] - xa[2] : xa[2] - xb[2];
+            const double slack = n0 * e0 + n1 * e1 + n2 * e2 - (a_lo ? ra + radius[b] : radius[b] + ra);
+            if (pinned) {
+                pin_viol = fmax(pin_viol, -slack);
+                continue;
+            }
+            if (need_da) {
+                const double f0 = w.dxa[((size_t)b * 3 + 0) * oq + j6], f1 = w.dxa[((size_t)b * 3 + 1) * oq + j6],
+                             f2 = w.dxa[((size_t)b * 3 + 2) * oq + j6];
+                gab = a_lo ? n0 * (da[0] - f0) + n1 * (da[1] - f1) + n2 * (da[2] - f2) : n0 * (f0 - da[0]) + n1 * (f1 - da[1]) + n2 * (f2 - da[2]);
+            }
+            if (need_dd) {
+                const double f0 = w.dx[((size_t)b * 3 + 0) * oq + j6], f1 = w.dx[((size_t)b * 3 + 1) * oq + j6],
+                             f2 = w.dx[((size_t)b * 3 + 2) * oq + j6];
+                gdb = a_lo ? n0 * (dd[0] - f0) + n1 * (dd[1] - f1) + n2 * (dd[2] - f2) : n0 * (f0 - dd[0]) + n1 * (f1 - dd[1]) + n2 * (f2 - dd[2]);
+            }
+            double wgt = 0, v = 0, zo = 0, sn = 0, zn = 0;
+            const double s = rd_sz ? ps[r] : 0.0, z = rd_sz ? pz[r] : 0.0;
+            row_op<PASS>(slack, gab, gdb, s, z, io, a_lo ? 1.0 : 0.0, wgt, v, zo, sn, zn);
+            if (wr_sz && a_lo) ps2[r] = sn, pz2[r] = zn;
+            if (accum) {
+                const double sg = a_lo ? 1.0 : -1.0;
+                if (build) {
+                    if (a_lo) w.pwgt[r] = wgt;
+                    Sm[0] += wgt * n0 * n0, Sm[1] += wgt * n0 * n1, Sm[2] += wgt * n0 * n2;
+                    Sm[3] += wgt * n1 * n1, Sm[4] += wgt * n1 * n2, Sm[5] += wgt * n2 * n2;
+                    const double zz = sg * zo, vv = sg * v;
+                    gz[0] += zz * n0, gz[1] += zz * n1, gz[2] += zz * n2;
+                    yv[0] += vv * n0, yv[1] += vv * n1, yv[2] += vv * n2;
+                } else {
+                    const double vv = sg * v, ww = sg * wgt;
+                    Sm[0] += vv * n0, Sm[1] += vv * n1, Sm[2] += vv * n2;
+                    Sm[3] += ww * n0, Sm[4] += ww * n1, Sm[5] += ww * n2;
+                }
+            }
+        }
+        if (accum && !pinned) {
+            double* acc = w.acc + (size_t)ch * 12 * ncp + (size_t)a * oq + j6;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) acc[(size_t)e * ncp] = Sm[e];
+            if (build) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc[(size_t)(6 + e) * ncp] = yv[e], acc[(size_t)(9 + e) * ncp] = gz[e];
+            }
+        }
+    }
+    // per-workgroup partials of the sweep's reductions (summed in a fixed order by the control kernels)
+    const int wg = blockIdx.x;
+    if (PASS == PASS_INIT) {
+        const double v = block_reduce(pin_viol, 1, red);
+        if (tid == 0) red_slot(w, A.L, RS_INIT, 0)[wg] = v;
+    } else if (PASS == PASS_BUILD || PASS == PASS_UPBUILD) {
+        const double g = block_reduce(io.sum0, 0, red), p = block_reduce(io.vmax, 1, red);
+        if (tid == 0) red_slot(w, A.L, RS_BUILD, 0)[wg] = g, red_slot(w, A.L, RS_BUILD, 1)[wg] = p;
+        if (PASS == PASS_UPBUILD) {
+            const double m = block_reduce(io.vmin, 2, red);
+            if (tid == 0) red_slot(w, A.L, RS_UP, 0)[wg] = m;
+        }
+    } else if (PASS == PASS_AFF) {
+        const double vm = block_reduce(io.vmax, 1, red), q0 = block_reduce(io.sum0, 0, red), q1 = block_reduce(io.sum1, 0, red),
+                     q2 = block_reduce(io.sum2, 0, red);
+        if (tid == 0) {
+            red_slot(w, A.L, RS_AFF, 0)[wg] = vm, red_slot(w, A.L, RS_AFF, 1)[wg] = q0;
+            red_slot(w, A.L, RS_AFF, 2)[wg] = q1, red_slot(w, A.L, RS_AFF, 3)[wg] = q2;
+        }
+    } else if (PASS == PASS_STEP) {
+        const double vm = block_reduce(io.vmax, 1, red);
+        if (tid == 0) red_slot(w, A.L, RS_STEP, 0)[wg] = vm;
+    }
+}
+
+// sum over the chunks' partial accumulators of component e at control point (a, j6)
+__device__ __forceinline__ double acc_sum(const Ws& w, const JDims& d, int e, size_t cp) {
+    double s = 0;
+    for (int c = 0; c < d.nch; ++c) s += w.acc[((size_t)c * 12 + e) * d.ncp + cp];
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// reduced-space right-hand sides.  One thread per (knot j, agent a, dim k):
+//   post<0>: rbase = -F'(2Qx + G'z), rhs = rbase + F'(G'v) (predictor), partials of max|rbase| and max|2Qx + G'z|
+//   post<1>: rhs = rbase + F'(part1 - sigma mu * part2)   (corrector; both parts were accumulated by the AFF sweep)
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CORR>
+__global__ __launch_bounds__(256) void jq_post(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    __shared__ double red[8];
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const JDims d = jdims(N, M);
+    const int oq = d.oq, nu = 3 * N;
+    const double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    const double sigma_mu = w.st[ST_SIGMU];
+    double dmax = 0, gmax = 0;
+    const int it = blockIdx.x * 256 + tid;
+    if (it < d.nj * nu) {
+        const int j = it / nu + 1, u = it % nu, a = u / 3, k = u % 3;
+        const double* L = w.Lk + 9 * j;
+        const size_t o0 = (size_t)(j - 1) * d.nkp + u * 3;
+        double g[6], y[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int j6 = 6 * (j - 1) + 3 + q;
+            const size_t cp = (size_t)a * oq + j6;
+            if (CORR) {
+                y[q] = acc_sum(w, d, k, cp) - sigma_mu * acc_sum(w, d, 3 + k, cp);
+            } else {
+                const int m = j6 / 6, i = j6 % 6;
+                const double* xs = ctrl + ((size_t)a * 3 + k) * oq + 6 * m;
+                double gv = 0;
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) gv += jc_Qbase[6 * i + jj] * xs[jj];
+                gv *= 2 * w.segsc[m];
+                gv += acc_sum(w, d, 9 + k, cp);
+                g[q] = -gv;
+                gmax = fmax(gmax, fabs(gv));
+                y[q] = acc_sum(w, d, 6 + k, cp);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            double rb;
+            if (CORR)
+                rb = w.rbase[o0 + e];
+            else {
+                rb = g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
+                w.rbase[o0 + e] = rb;
+                dmax = fmax(dmax, fabs(rb));
+            }
+            w.rhs[o0 + e] = rb + y[3 + e] + L[0 + e] * y[0] + L[3 + e] * y[1] + L[6 + e] * y[2];
+        }
+    }
+    if (!CORR) {
+        const double dm = block_reduce(dmax, 1, red), gm = block_reduce(gmax, 1, red);
+        if (tid == 0) red_slot(w, A.L, RS_POST, 0)[blockIdx.x] = dm, red_slot(w, A.L, RS_POST, 1)[blockIdx.x] = gm;
+    }
+}
+
+// dx[a][k][j6] = F du (du = the solution left in rhs); which: 0 -> dxa, 1 -> dx
+__global__ __launch_bounds__(256) void jq_apply_F(JArgs A, int which) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const int N = S.N, M = S.Mk[mission];
+    const JDims d = jdims(N, M);
+    const int nu = 3 * N, it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= d.nj * nu) return;
+    const int j = it / nu + 1, u = it % nu;
+    const double* uu = w.rhs + (size_t)(j - 1) * d.nkp + u * 3;
+    const double* L = w.Lk + 9 * j;
+    const double u0 = uu[0], u1 = uu[1], u2 = uu[2];
+    double* o = (which ? w.dx : w.dxa) + (size_t)u * d.oq + 6 * (j - 1) + 3;
+    o[0] = L[0] * u0 + L[1] * u1 + L[2] * u2;
+    o[1] = L[3] * u0 + L[4] * u1 + L[5] * u2;
+    o[2] = L[6] * u0 + L[7] * u1 + L[8] * u2;
+    o[3] = u0, o[4] = u1, o[5] = u2;
+}
+
+// x += (alpha - applied) dx
+__global__ __launch_bounds__(256) void jq_stepx(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0) return;
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const int nx = N * 3 * 6 * M, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nx) return;
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    ctrl[i] += (w.st[ST_ALPHA] - w.st[ST_APPLIED]) * w.dx[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// control kernels: one workgroup per mission finishes the reductions and takes the decisions of the interior-point loop
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ inline double red_final(const double* part, int n, int op, double init, double* red) {
+    double v = init;
+    for (int i = threadIdx.x; i < n; i += 256) v = red_op(v, part[i], op);
+    return block_reduce(v, op, red);
+}
+
+// which: 0 = after INIT (pinned rows), 1 = top of an iteration (first: gap / pres come from the BUILD sweep), 2 = after AFF,
+// 3 = after STEP, 4 = after UPBUILD
+__global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.x, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    __shared__ double red[8];
+    double* st = w.st;
+    if (st[ST_STATE] != 0.0) return;
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const int nsw = S.N * d.nch, npost = (d.nj * 3 * S.N + 255) / 256;
+    const double nrows = st[ST_NROWS];
+    if (which == 0) {
+        const double pv = red_final(red_slot(w, A.L, RS_INIT, 0), nsw, 1, 0.0, red);
+        if (tid == 0 && pv > 1e-6) st[ST_STATE] = 2.0, st[ST_REASON] = 1.0, st[ST_KKT] = pv;  // a constant (pinned) row is violated
+    } else if (which == 1) {
+        if (st[ST_RETRY] != 0.0) return;
+        double gap = st[ST_GAP], pres = st[ST_PRES];
+        if (first) {
+            gap = red_final(red_slot(w, A.L, RS_BUILD, 0), nsw, 0, 0.0, red);
+            pres = red_final(red_slot(w, A.L, RS_BUILD, 1), nsw, 1, 0.0, red);
+        }
+        const double dmax = red_final(red_slot(w, A.L, RS_POST, 0), npost, 1, 0.0, red);
+        const double gmax = red_final(red_slot(w, A.L, RS_POST, 1), npost, 1, 0.0, red);
+        if (tid == 0) {
+            const double dres = dmax / (1.0 + gmax), mu = gap / nrows;
+            st[ST_GAP] = gap, st[ST_PRES] = pres, st[ST_DRES] = dres, st[ST_MU] = mu;
+            st[ST_KKT] = fmax(pres, fmax(dres, mu));
+            const bool ok = (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
+                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-14);  // (the three exits of qp.hip)
+            if (ok)
+                st[ST_STATE] = 1.0;
+            else if (!(gap == gap) || st[ST_ITER] >= JQ_MAX_ITERS)
+                st[ST_STATE] = 2.0, st[ST_REASON] = 3.0;  // iteration cap (or NaN)
+            else
+                st[ST_ITER] += 1.0;
+        }
+    } else if (which == 2) {
+        if (st[ST_RETRY] != 0.0) return;
+        const double vm = red_final(red_slot(w, A.L, RS_AFF, 0), nsw, 1, 1.0, red);
+        const double q0 = red_final(red_slot(w, A.L, RS_AFF, 1), nsw, 0, 0.0, red);
+        const double q1 = red_final(red_slot(w, A.L, RS_AFF, 2), nsw, 0, 0.0, red);
+        const double q2 = red_final(red_slot(w, A.L, RS_AFF, 3), nsw, 0, 0.0, red);
+        if (tid == 0) {
+            const double a_aff = 1.0 / vm, mu = st[ST_MU];
+            const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows;
+            double sigma = mu_aff / mu;
+            sigma = sigma * sigma * sigma;
+            st[ST_SIGMU] = sigma * mu, st[ST_AAFF] = a_aff;
+        }
+    } else if (which == 3) {
+        if (st[ST_RETRY] != 0.0) return;
+        const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, JQ_STEP_FRAC, red);
+        if (tid == 0) st[ST_ALPHA] = JQ_STEP_FRAC / vm, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
+    } else if (which == 4) {
+        const double gap = red_final(red_slot(w, A.L, RS_BUILD, 0), nsw, 0, 0.0, red);
+        const double pres = red_final(red_slot(w, A.L, RS_BUILD, 1), nsw, 1, 0.0, red);
+        const double pmin = red_final(red_slot(w, A.L, RS_UP, 0), nsw, 2, 1e300, red);
+        if (tid == 0) {
+            if (pmin >= JQ_NBHD_GAMMA * gap / nrows || st[ST_BT] >= 40.0 || !(gap == gap)) {
+                st[ST_PAR] = 1.0 - st[ST_PAR], st[ST_RETRY] = 0.0, st[ST_GAP] = gap, st[ST_PRES] = pres;
+            } else {  // wide-neighbourhood test failed: repeat the update sweep from the (untouched) old state with 0.8 alpha
+                st[ST_APPLIED] = st[ST_ALPHA], st[ST_ALPHA] *= 0.8, st[ST_RETRY] = 1.0, st[ST_BT] += 1.0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// factorisation
+// ------------------------------------------------------------------------------------------------------------------------
+// chain geometry of a mission: mid = nj / 2; chain 0 eliminates knots 0 .. mid-1 upwards, chain 1 knots nj-1 .. mid+1 downwards
+struct Chain {
+    bool active;
+    int jj;    // 0-based knot of this step
+    int prev;  // knot whose inverse feeds the Schur update (-1: none)
+};
+__device__ __forceinline__ Chain chain_step(const JDims& d, int chain, int s, bool mid) {
+    Chain c;
+    const int m = d.nj / 2, nl = m, nr = d.nj - 1 - m;
+    if (mid) {
+        c.active = chain == 0, c.jj = m, c.prev = -1;
+    } else if (chain == 0) {
+        c.active = s < nl, c.jj = s, c.prev = s > 0 ? s - 1 : -1;
+    } else {
+        c.active = s < nr, c.jj = d.nj - 1 - s, c.prev = s > 0 ? d.nj - s : -1;
+    }
+    return c;
+}
+// ping-pong buffers of the sweep: X[0] = the knot's slot in `inv`, X[1] = the chain's scratch; step k reads X[(k + p0) & 1] and writes
+// the other; p0 = nblk & 1 makes the last step land in X[0]
+__device__ __forceinline__ double* sweep_buf(const Ws& w, const JDims& d, const JLayout& L, int chain, int jj, int which) {
+    return which == 0 ? w.inv + (size_t)jj * L.nkpS * L.nkpS : w.scr + (size_t)chain * L.nkpS * L.nkpS;
+}
+
+// T_jj + Schur updates, written into the first sweep buffer (tiles I >= J).  One thread per 3x3 block (Ai, Bi) = ((a, k), (b, l)).
+__global__ __launch_bounds__(256) void jq_prep(JArgs A, int s, int mid) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const JDims d = jdims(N, M);
+    const Chain c = chain_step(d, chain, s, mid != 0);
+    if (!c.active) return;
+    const int jj = c.jj, j = jj + 1, nblk = d.nblk, oq = d.oq, n3 = 3 * N;
+    double* X = sweep_buf(w, d, A.L, chain, jj, (nblk & 1));
+    const float* normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    // identity padding (rows / columns nk .. nkp-1)
+    const int npad = d.nkp - d.nk;
+    for (int i = t; i < npad * d.nkp; i += gridDim.x * 256) {
+        const int r = d.nk + i / d.nkp, cc = i % d.nkp;
+        X[telem(nblk, r, cc)] = r == cc ? 1.0 : 0.0;
+        if ((cc >> 6) == nblk - 1) X[telem(nblk, cc, r)] = r == cc ? 1.0 : 0.0;
+    }
+    if (t >= n3 * n3) return;
+    const int Ai = t / n3, Bi = t % n3;
+    if ((3 * Ai + 2) / JT < (3 * Bi) / JT) return;  // no entry of this block lies in a tile I >= J
+    const int a = Ai / 3, k = Ai % 3, b = Bi / 3, l = Bi % 3;
+    double Sv[6];
+    if (a == b) {
+        const int kk = k < l ? k : l, ll = k < l ? l : k, sym = kk == 0 ? ll : (kk == 1 ? 2 + ll : 5);
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) Sv[pp] = acc_sum(w, d, sym, (size_t)a * oq + 6 * (j - 1) + 3 + pp);
+    } else {
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        const size_t pi = pair_index(N, lo, hi);
+        const float* nl = normals + (pi * M + (j - 1)) * 3;
+        const float* nr = normals + (pi * M + j) * 3;
+        const double nnl = (double)nl[k] * (double)nl[l], nnr = (double)nr[k] * (double)nr[l];
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) Sv[pp] = -w.pwgt[pi * oq + 6 * (j - 1) + 3 + pp] * (pp < 3 ? nnl : nnr);
+    }
+    const double* L = w.Lk + 9 * j;
+    double out[9];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
+            if (e == f) acc += Sv[3 + e];
+            if (Ai == Bi) acc += w.Dk[9 * j + 3 * e + f];
+            out[3 * e + f] = acc;
+        }
+    // Schur updates: - Cm Inv_prev Cm'  with the 3x3 coupling block Cm (the same for every (agent, dim))
+    for (int side = 0; side < 2; ++side) {
+        int prev;
+        if (mid)
+            prev = side == 0 ? (jj > 0 ? jj - 1 : -1) : (jj + 1 < d.nj ? jj + 1 : -1);
+        else
+            prev = side == 0 ? c.prev : -1;
+        if (prev < 0) continue;
+        double Cm[9];  // Cm[e][e']: row component e of knot jj, column component e' of knot prev
+        if (prev < jj) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+#pragma unroll
+                for (int e2 = 0; e2 < 3; ++e2) Cm[3 * e + e2] = w.Ek[9 * jj + 3 * e2 + e];  // C_{jj-1}[r][c] = Ek[9 jj + 3 c + r]
+        } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+#pragma unroll
+                for (int e2 = 0; e2 < 3; ++e2) Cm[3 * e + e2] = w.Ek[9 * (jj + 1) + 3 * e + e2];  // C_jj'[e][e'] = C_jj[e'][e]
+        }
+        const double* Ip = w.inv + (size_t)prev * A.L.nkpS * A.L.nkpS;
+        double V[9];
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) V[3 * e + f] = Ip[telem(nblk, 3 * Ai + e, 3 * Bi + f)];
+        double CV[9];
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) CV[3 * e + f] = Cm[3 * e] * V[f] + Cm[3 * e + 1] * V[3 + f] + Cm[3 * e + 2] * V[6 + f];
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) out[3 * e + f] -= CV[3 * e] * Cm[3 * f] + CV[3 * e + 1] * Cm[3 * f + 1] + CV[3 * e + 2] * Cm[3 * f + 2];
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int r = 3 * Ai + e, cc = 3 * Bi + f;
+            if ((r >> 6) >= (cc >> 6)) X[telem(nblk, r, cc)] = out[3 * e + f];
+        }
+}
+
+// ---- 64 x 64 SPD inverse in LDS (256 threads): the same blocked sweep one level down, 16 x 16 sub-tiles on the MFMA, the diagonal
+// sub-tile by Gauss-Jordan with the rows in lanes (v_readlane broadcasts).  In: Am = the SPD tile, leading dimension LDA.
+// Out: Am = -(tile)^-1.  *bad is set when a pivot is not positive.
+constexpr int LDA = 66;  // (ds_read_b64 of lane (i, g) at row i, column 4 kk + g: conflict free with 66)
+__device__ __forceinline__ double rl(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+struct InvScratch {
+    double Pi[16 * 18];
+    double Yb[4][16 * 18];
+    double Zb[4][16 * 18];
+};
+__device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    for (int kk = 0; kk < 4; ++kk) {
+        if (wave == 0) {  // Gauss-Jordan inverse of the 16 x 16 diagonal sub-tile: row li in lane li (lanes >= 16 carry copies)
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = Am[(16 * kk + li) * LDA + 16 * kk + c];
+            bool okp = true;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double p = rl(a[c], c);
+                okp = okp && (p > 0.0);
+                const double ip = fast_rcp(p);
+                const double f = a[c];
+                double rc[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) rc[q] = rl(a[q], c) * ip;
+                if (li == c) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a[q] = rc[q];
+                    a[c] = ip;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) a[q] -= f * rc[q];
+                    a[c] = -f * ip;
+                }
+            }
+            if (!okp && lane == 0) *bad = 1;
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sc->Pi[li * 18 + c] = a[c];
+            }
+        }
+        __syncthreads();
+        // panel: row block i = wave: Z = A[i][kk] (old), Y = Z Pi'
+        if (wave != kk) {
+            d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double av = Am[(16 * wave + li) * LDA + 16 * kk + 4 * q + lg];
+                const double bv = sc->Pi[li * 18 + 4 * q + lg];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc->Yb[wave][(lg + 4 * r) * 18 + li] = acc[r];
+                sc->Zb[wave][(lg + 4 * r) * 18 + li] = Am[(16 * wave + lg + 4 * r) * LDA + 16 * kk + li];
+            }
+        }
+        __syncthreads();
+        // update: row block i = wave, all four column blocks
+        for (int jb = 0; jb < 4; ++jb) {
+            double* At = Am + (16 * wave) * LDA + 16 * jb;
+            if (wave == kk && jb == kk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = -sc->Pi[(lg + 4 * r) * 18 + li];
+            } else if (jb == kk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = sc->Yb[wave][(lg + 4 * r) * 18 + li];
+            } else if (wave == kk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = sc->Yb[jb][li * 18 + lg + 4 * r];
+            } else {
+                d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double av = sc->Yb[wave][li * 18 + 4 * q + lg];
+                    const double bv = sc->Zb[jb][li * 18 + 4 * q + lg];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] -= acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Pbuf[chain][parity] <- symmetrised inverse of the SPD tile held (as its NEGATED inverse after inv64_lds) in Am
+__device__ __forceinline__ void store_pivot_inverse(const double* Am, double* Pg) {
+    for (int i = threadIdx.x; i < JTT; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        Pg[i] = -0.5 * (Am[r * LDA + c] + Am[c * LDA + r]);
+    }
+}
+
+// first pivot of a knot (the others are inverted by the update kernel's look-ahead)
+__global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int s, int mid) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const Chain c = chain_step(d, chain, s, mid != 0);
+    if (!c.active) return;
+    __shared__ double Am[JT * LDA];
+    __shared__ InvScratch sc;
+    __shared__ int bad;
+    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (d.nblk & 1));
+    if (threadIdx.x == 0) bad = 0;
+    for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = X[i];  // tile (0, 0)
+    __syncthreads();
+    inv64_lds(Am, &sc, &bad);
+    store_pivot_inverse(Am, w.P + ((size_t)chain * 2 + 0) * JTT);
+    if (bad && threadIdx.x == 0) w.st[ST_STATE] = 2.0, w.st[ST_REASON] = 2.0;  // Newton matrix not positive definite
+}
+
+// operand fragments of a 16-row block for v_mfma_f64_16x16x4_f64 over K = 64: lane (i, g) holds rows[i][16 ch + 4 g + q], ch, q = 0..3
+// (the four MFMA steps of a 16-chunk use k = 4 g + q on both operands: a permutation of the summation index, see tile_nt in qp.hip).
+// TR: the operand is the TRANSPOSE of the stored tile (rows of the operand are columns of the tile).
+__device__ __forceinline__ void load_frag(const double* tile, int row0, bool tr, int li, int lg, d4 (&f)[4]) {
+    if (!tr) {
+        const double* p = tile + (size_t)(row0 + li) * JT + 4 * lg;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) f[ch] = *reinterpret_cast<const d4*>(p + 16 * ch);
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[ch][q] = tile[(size_t)(16 * ch + 4 * lg + q) * JT + row0 + li];
+    }
+}
+
+// panel of step k: Y_J = B_Jk P for every J != k  (B_Jk = tile (J, k) below the pivot, tile (k, J)' left of it)
+__global__ __launch_bounds__(256) void jq_panel(JArgs A, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y, J = blockIdx.x;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const Chain c = chain_step(d, chain, s, mid != 0);
+    if (!c.active || J >= d.nblk || J == k) return;
+    const int nblk = d.nblk, p0 = nblk & 1;
+    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (k + p0) & 1);
+    const double* P = w.P + ((size_t)chain * 2 + (k & 1)) * JTT;
+    const bool tr = J < k;
+    const double* Z = X + (tr ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
+    double* Y = w.Y + ((size_t)chain * A.L.nblkS + J) * JTT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    d4 zf[4];
+    load_frag(Z, 16 * wave, tr, li, lg, zf);  // rows 16 wave .. of Z_J
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        d4 pf[4];
+        load_frag(P, 16 * tj, false, li, lg, pf);  // P symmetric: Z P = Z P'
+        d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[ch][q], pf[ch][q], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[(size_t)(16 * wave + lg + 4 * r) * JT + 16 * tj + li] = acc[r];
+    }
+}
+
+// update of step k: every tile (I, J), I >= J, of the lower triangle
+//   (k, k) <- -P        (I, k) <- Y_I        (k, J) <- Y_J'        else  B_IJ - Y_I B_Jk'
+// The last step writes -(...) = the inverse itself, with both triangles.  Look-ahead: the workgroup of tile (k+1, k+1) inverts it.
+__global__ __launch_bounds__(256) void jq_update(JArgs A, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const Chain c = chain_step(d, chain, s, mid != 0);
+    const int nblk = d.nblk;
+    if (!c.active || (int)blockIdx.x >= nblk * (nblk + 1) / 2) return;
+    int I = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    if (I * (I + 1) / 2 > (int)blockIdx.x) I--;
+    if ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
+    const int J = blockIdx.x - I * (I + 1) / 2;
+    const int p0 = nblk & 1;
+    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (k + p0) & 1);
+    double* Xn = sweep_buf(w, d, A.L, chain, c.jj, (k + p0 + 1) & 1);
+    const double* P = w.P + ((size_t)chain * 2 + (k & 1)) * JTT;
+    const double* Yb = w.Y + (size_t)chain * A.L.nblkS * JTT;
+    const bool last = k == nblk - 1, look = !last && I == k + 1 && J == k + 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;  // this wave's 32 x 32 quadrant
+    __shared__ double Am[JT * LDA];
+    __shared__ InvScratch sc;
+    __shared__ int bad;
+    double* out = Xn + ((size_t)I * nblk + J) * JTT;
+    double* outT = Xn + ((size_t)J * nblk + I) * JTT;
+    const double sgn = last ? -1.0 : 1.0;
+    if (I == k || J == k) {  // copies (through LDS for the transposed ones)
+        const double* src = (I == k && J == k) ? P : (J == k ? Yb + (size_t)I * JTT : Yb + (size_t)J * JTT);
+        const bool tr = (I == k && J != k);
+        const double f = (I == k && J == k) ? -sgn : sgn;
+        for (int i = tid; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = src[i];
+        __syncthreads();
+        for (int i = tid; i < JTT; i += 256) {
+            const int r = i >> 6, cc = i & 63;
+            const double v = f * (tr ? Am[cc * LDA + r] : Am[r * LDA + cc]);
+            out[i] = v;
+            if (last && I != J) outT[(size_t)cc * JT + r] = v;
+        }
+        return;
+    }
+    const bool trJ = J < k;
+    const double* Zt = X + (trJ ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
+    const double* Yt = Yb + (size_t)I * JTT;
+    const double* Ct = X + ((size_t)I * nblk + J) * JTT;
+    d4 yf[2][4], zf[2][4];
+    load_frag(Yt, 32 * wr, false, li, lg, yf[0]);
+    load_frag(Yt, 32 * wr + 16, false, li, lg, yf[1]);
+    load_frag(Zt, 32 * wc, trJ, li, lg, zf[0]);
+    load_frag(Zt, 32 * wc + 16, trJ, li, lg, zf[1]);
+    double cv[2][2][4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[ti][tj][r] = Ct[(size_t)(32 * wr + 16 * ti + lg + 4 * r) * JT + 32 * wc + 16 * tj + li];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[ti][ch][q], zf[tj][ch][q], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[ti][tj][r] = sgn * (cv[ti][tj][r] - acc[r]);
+        }
+    if (!(last && I != J) && !look) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(32 * wr + 16 * ti + lg + 4 * r) * JT + 32 * wc + 16 * tj + li] = cv[ti][tj][r];
+        return;
+    }
+    // through LDS: mirrored store of the last step / look-ahead inversion of the next pivot
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Am[(32 * wr + 16 * ti + lg + 4 * r) * LDA + 32 * wc + 16 * tj + li] = cv[ti][tj][r];
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int i = tid; i < JTT; i += 256) {
+        const int r = i >> 6, cc = i & 63;
+        out[i] = Am[r * LDA + cc];
+        if (last) outT[i] = Am[cc * LDA + r];
+    }
+    if (look) {
+        __syncthreads();
+        inv64_lds(Am, &sc, &bad);
+        store_pivot_inverse(Am, w.P + ((size_t)chain * 2 + ((k + 1) & 1)) * JTT);
+        if (bad && tid == 0) w.st[ST_STATE] = 2.0, w.st[ST_REASON] = 2.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// substitutions with the stored inverses.  mode 0 forward (w_j = S_j^-1 (r_j - C w_prev)), 1 middle (x_m = S_m^-1 (r_m - C w_l -
+// C' w_r)), 2 backward (x_j = w_j - S_j^-1 C' x_next).  The solution replaces rhs.  One workgroup per 16-row slab.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const Chain c = chain_step(d, chain, s, mode == 1);
+    if (!c.active || (int)blockIdx.x * 16 >= d.nkp) return;
+    const int jj = c.jj, nkp = d.nkp, nk = d.nk, nblk = d.nblk;
+    extern __shared__ double vsh[];  // nkp
+    const double* rj = w.rhs + (size_t)jj * nkp;
+    for (int i = tid; i < nkp; i += 256) {
+        double v = 0;
+        if (i < nk) {
+            const int u3 = (i / 3) * 3, e = i % 3;
+            if (mode == 0) {
+                v = rj[i];
+                if (c.prev >= 0) {
+                    const double* wp = w.wv + (size_t)c.prev * nkp + u3;
+                    if (c.prev < jj)
+                        v -= w.Ek[9 * jj + e] * wp[0] + w.Ek[9 * jj + 3 + e] * wp[1] + w.Ek[9 * jj + 6 + e] * wp[2];
+                    else
+                        v -= w.Ek[9 * (jj + 1) + 3 * e] * wp[0] + w.Ek[9 * (jj + 1) + 3 * e + 1] * wp[1] + w.Ek[9 * (jj + 1) + 3 * e + 2] * wp[2];
+                }
+            } else if (mode == 1) {
+                v = rj[i];
+                if (jj > 0) {
+                    const double* wp = w.wv + (size_t)(jj - 1) * nkp + u3;
+                    v -= w.Ek[9 * jj + e] * wp[0] + w.Ek[9 * jj + 3 + e] * wp[1] + w.Ek[9 * jj + 6 + e] * wp[2];
+                }
+                if (jj + 1 < d.nj) {
+                    const double* wp = w.wv + (size_t)(jj + 1) * nkp + u3;
+                    v -= w.Ek[9 * (jj + 1) + 3 * e] * wp[0] + w.Ek[9 * (jj + 1) + 3 * e + 1] * wp[1] + w.Ek[9 * (jj + 1) + 3 * e + 2] * wp[2];
+                }
+            } else {
+                // the knot towards the middle: chain 0 -> jj + 1, chain 1 -> jj - 1 (its solution is already in rhs)
+                if (chain == 0) {
+                    const double* xp = w.rhs + (size_t)(jj + 1) * nkp + u3;
+                    v = w.Ek[9 * (jj + 1) + 3 * e] * xp[0] + w.Ek[9 * (jj + 1) + 3 * e + 1] * xp[1] + w.Ek[9 * (jj + 1) + 3 * e + 2] * xp[2];
+                } else {
+                    const double* xp = w.rhs + (size_t)(jj - 1) * nkp + u3;
+                    v = w.Ek[9 * jj + e] * xp[0] + w.Ek[9 * jj + 3 + e] * xp[1] + w.Ek[9 * jj + 6 + e] * xp[2];
+                }
+            }
+        }
+        vsh[i] = v;
+    }
+    __syncthreads();
+    const double* Inv = w.inv + (size_t)jj * A.L.nkpS * A.L.nkpS;
+    const int row = blockIdx.x * 16 + (tid >> 4), l16 = tid & 15;
+    const double* rp = Inv + ((size_t)(row >> 6) * nblk) * JTT + (size_t)(row & 63) * JT + 4 * l16;
+    double acc = 0;
+    for (int Jt = 0; Jt < nblk; ++Jt) {
+        const d4 m = *reinterpret_cast<const d4*>(rp + (size_t)Jt * JTT);
+        const double* vv = vsh + 64 * Jt + 4 * l16;
+        acc += m[0] * vv[0] + m[1] * vv[1] + m[2] * vv[2] + m[3] * vv[3];
+    }
+    acc += __shfl_xor(acc, 8), acc += __shfl_xor(acc, 4), acc += __shfl_xor(acc, 2), acc += __shfl_xor(acc, 1);
+    if (l16 == 0 && row < nk) {
+        if (mode == 0)
+            w.wv[(size_t)jj * nkp + row] = acc;
+        else if (mode == 1)
+            w.rhs[(size_t)jj * nkp + row] = acc;
+        else
+            w.rhs[(size_t)jj * nkp + row] = w.wv[(size_t)jj * nkp + row] - acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// end of a solve: objective sum x' Q_p x (cplex.getObjValue, rbp_planner.hpp:164), diagnostics, status
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jq_finish(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.x, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    __shared__ double red[8];
+    const int N = S.N, M = S.Mk[mission], MS = S.M, oq = 6 * M;
+    if (S.status[mission] != 0) return;
+    double* scal = S.scalars + (size_t)mission * SC_N;
+    if (w.st[ST_STATE] != 1.0) {
+        if (tid == 0) {
+            atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
+            scal[SC_PROF0 + 1] = w.st[ST_REASON], scal[SC_PROF0 + 2] = w.st[ST_ITER];
+        }
+        return;
+    }
+    const double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    double obj = 0;
+    for (int it = tid; it < N * 3 * M; it += 256) {
+        const int a = it / (3 * M), k = (it / M) % 3, m = it % M;
+        const double* xs = ctrl + ((size_t)a * 3 + k) * oq + 6 * m;
+        double q = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int jj = 0; jj < 6; ++jj) q += jc_Qbase[6 * i + jj] * xs[i] * xs[jj];
+        obj += q * w.segsc[m];
+    }
+    obj = block_reduce(obj, 0, red);
+    if (tid == 0) {
+        scal[SC_TOTAL_COST] = obj;
+        scal[SC_IPM_ITERS] += w.st[ST_ITER];
+        scal[SC_QP_SOLVED] += 1;
+        scal[SC_POLISHED] += w.st[ST_POLISHED];
+        scal[SC_KKT_MAX] = fmax(scal[SC_KKT_MAX], w.st[ST_KKT]);
+        scal[SC_FLOPS] += w.st[ST_FLOPS];
+        scal[SC_ROWS] += w.st[ST_NROWS] * (1.0 + 4.0 * w.st[ST_ITER]);
+    }
+}
+
+// logged flops of one factorisation (the MFMA work actually issued: panels and rank-64 updates of the lower triangle) and of the two
+// solves of an iteration
+__global__ void jq_count(JArgs A) {
+    const int mission = blockIdx.x;
+    const Ws w = carve(A, mission);
+    if (threadIdx.x != 0 || w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    const JDims d = jdims(A.S.N, A.S.Mk[mission]);
+    const double nb = d.nblk, per_knot = nb * ((nb - 1) * nb / 2 + (nb - 1)) * 2.0 * JT * JT * JT;
+    w.st[ST_FLOPS] += d.nj * per_knot + 2.0 * (2.0 * d.nj - 1.0) * 2.0 * (double)d.nkp * d.nkp;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------
+JLayout jq_layout(int N, int MS) {
+    JLayout L{};
+    const JDims d = jdims(N, MS);
+    L.N = N, L.MS = MS, L.nkpS = d.nkp, L.nblkS = d.nblk, L.njS = d.nj, L.nch = d.nch;
+    L.nred = std::max(N * d.nch, (d.nj * 3 * N + 255) / 256);
+    size_t o = 0;
+    auto take = [&](size_t n) {
+        const size_t r = o;
+        o += (n + 31) & ~size_t(31);  // 256-byte granules
+        return r;
+    };
+    const size_t ncp = (size_t)N * d.oq, nrow = (size_t)d.npair * d.oq;
+    L.o_state = take(ST_N);
+    L.o_segsc = take(MS), L.o_Lk = take(9 * (MS + 1)), L.o_Dk = take(9 * (MS + 1)), L.o_Ek = take(9 * (MS + 1));
+    L.o_boxlo = take((size_t)N * MS * 3), L.o_boxhi = take((size_t)N * MS * 3);
+    L.o_dxa = take(3 * ncp), L.o_dx = take(3 * ncp);
+    L.o_rbase = take((size_t)d.nj * d.nkp), L.o_rhs = take((size_t)d.nj * d.nkp), L.o_wv = take((size_t)d.nj * d.nkp);
+    L.o_red = take((size_t)RS_NSLOT * 4 * L.nred);
+    L.zero_doubles = o;  // everything up to here is cleared at the start of a run
+    for (int p = 0; p < 2; ++p) L.o_bs[p] = take(6 * ncp), L.o_bz[p] = take(6 * ncp), L.o_ps[p] = take(nrow), L.o_pz[p] = take(nrow);
+    L.o_pwgt = take(nrow);
+    L.o_acc = take((size_t)d.nch * 12 * ncp);
+    L.o_Y = take((size_t)2 * d.nblk * JTT), L.o_P = take((size_t)4 * JTT);
+    L.o_scr = take((size_t)2 * d.nkp * d.nkp);
+    L.o_inv = take((size_t)d.nj * d.nkp * d.nkp);
+    L.stride = o;
+    return L;
+}
+
+size_t joint_workspace_bytes(int N, int MS) { return jq_layout(N, MS).stride * sizeof(double); }
+
+#define JQ_LAUNCH(kern, grid, lds, ...) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, __VA_ARGS__)
+
+// One joint QP per mission of the session.  Synchronises the stream once per interior-point iteration (to learn whether any mission is
+// still running); everything else is enqueued.
+int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats) {
+    JArgs A;
+    A.S = s, A.ws = (double*)ws, A.L = jq_layout(s.N, s.M);
+    const JLayout& L = A.L;
+    const int K = s.K, N = s.N;
+    const JDims dm = jdims(N, s.M);  // the session's largest mission
+    const int nsw = N * dm.nch, npost = (dm.nj * 3 * N + 255) / 256, nblk = dm.nblk, ntri = nblk * (nblk + 1) / 2;
+    const int mid_max = dm.nj / 2, steps = std::max(mid_max, dm.nj - 1 - mid_max);
+    const int nxblk = (N * 3 * dm.oq + 255) / 256, nprep = (9 * N * N + 255) / 256;
+    for (int k = 0; k < K; ++k)
+        if (hipMemsetAsync(A.ws + (size_t)k * L.stride, 0, L.zero_doubles * sizeof(double), st) != hipSuccess) return RBP_ERR_HIP;
+    JQ_LAUNCH(jq_setup, dim3(K), 0, A);
+    JQ_LAUNCH(jq_sweep<PASS_INIT>, dim3(nsw, K), 0, A);
+    JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 0, 0);
+    std::vector<double> state((size_t)K);
+    double* state_h = nullptr;
+    if (hipHostMalloc((void**)&state_h, sizeof(double) * K * ST_N) != hipSuccess) return RBP_ERR_HIP;
+    auto solve = [&](int which_out) {
+        for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 0, sidx);
+        JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 1, 0);
+        for (int sidx = steps - 1; sidx >= 0; --sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 2, sidx);
+        JQ_LAUNCH(jq_apply_F, dim3(npost, K), 0, A, which_out);
+    };
+    auto factor_knot = [&](int sidx, int mid) {
+        const int nchain = mid ? 1 : 2;
+        JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
+        JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, sidx, mid);
+        for (int k = 0; k < nblk; ++k) {
+            if (nblk > 1) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, sidx, mid, k);
+            JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, sidx, mid, k);
+        }
+    };
+    int iters = 0, rc = RBP_OK;
+    const int max_rounds = JQ_MAX_ITERS + 48;
+    for (int it = 0; it < max_rounds; ++it) {
+        if (it == 0) JQ_LAUNCH(jq_sweep<PASS_BUILD>, dim3(nsw, K), 0, A);
+        JQ_LAUNCH(jq_post<0>, dim3(npost, K), 0, A);
+        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 1, (int)(it == 0));
+        // is any mission still running?  (one synchronisation per iteration)
+        if (hipMemcpy2DAsync(state_h, sizeof(double) * ST_N, A.ws + L.o_state, L.stride * sizeof(double), sizeof(double) * ST_N, K,
+                             hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            rc = RBP_ERR_HIP;
+            break;
+        }
+        bool running = false;
+        for (int k = 0; k < K; ++k) running = running || state_h[(size_t)k * ST_N + ST_STATE] == 0.0;
+        if (!running) break;
+        iters++;
+        JQ_LAUNCH(jq_count, dim3(K), 0, A);
+        for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
+        factor_knot(0, 1);
+        solve(0);
+        JQ_LAUNCH(jq_sweep<PASS_AFF>, dim3(nsw, K), 0, A);
+        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 2, 0);
+        JQ_LAUNCH(jq_post<1>, dim3(npost, K), 0, A);
+        solve(1);
+        JQ_LAUNCH(jq_sweep<PASS_STEP>, dim3(nsw, K), 0, A);
+        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 3, 0);
+        JQ_LAUNCH(jq_stepx, dim3(nxblk, K), 0, A);
+        JQ_LAUNCH(jq_sweep<PASS_UPBUILD>, dim3(nsw, K), 0, A);
+        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
+    }
+    JQ_LAUNCH(jq_finish, dim3(K), 0, A);
+    if (stats) stats->rounds = iters;
+    (void)hipHostFree(state_h);
+    if (hipGetLastError() != hipSuccess) rc = RBP_ERR_HIP;
+    return rc;
+}

@@ -1257,6 +1257,7 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
     const int nl = mid, nr = d.nj - 1 - mid, SF = nl > nr ? nl : nr;
     constexpr int AREA = KlArea<NK>::SIZE;    // one chain wave's LDS area (knot_lds.inc)
     int* cnt = (int*)(lds + 2 * AREA);  // [SF + 1] assembly counters, then (at +64) the chains' progress words
+    static_assert((QP_MAX_M - 1) / 2 + 1 <= 64, "cnt[0..SF] must end below CHAIN_SYNC (cnt + 64): sessions with M > QP_MAX_M are refused");
     if (threadIdx.x == 0) *flag = 0;
     __syncthreads();
     bool ok = true;
@@ -2880,6 +2881,20 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
 size_t QP_CAT(planner_workspace_bytes, QP_SUFFIX)(int N, int M, int batch_size_eff) {
     return (ws_doubles(N, M, batch_size_eff) * sizeof(double) + 255) & ~size_t(255);
 }
+
+#if QP_THREADS == 512
+// build_dummy in front of, Bernstein -> monomial + timeScale behind the grid-wide joint QP (kernels/jqp.hip), which has no copies of
+// these kernels (exported by the 512-thread build only)
+void launch_planner_prologue(const DevSession& s, hipStream_t st) {
+    const size_t total = (size_t)s.K * s.N * 3 * 6 * s.M;
+    hipLaunchKernelGGL(dummy_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, s);
+}
+void launch_planner_epilogue(const DevSession& s, hipStream_t st) {
+    const size_t tot2 = (size_t)s.K * s.N * 3 * s.M;
+    hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(timescale_kernel, dim3(s.K), dim3(256), 0, st, s);
+}
+#endif
 
 void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st) {
     const int N = s.N, M = s.M;

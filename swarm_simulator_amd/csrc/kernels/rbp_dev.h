@@ -21,6 +21,7 @@
 #define SP_EPSILON 1e-9        /* reference: swarm_planner/include/sp_const.hpp:3 */
 #define SP_EPSILON_FLOAT 1e-6  /* sp_const.hpp:4 */
 #define QP_MAX_NB 64           /* widest batch (agents) one workgroup factorises: nk = 9 * 64 = 576 */
+#define QP_MAX_M 128           /* most segments per mission the QP kernel takes: 64 LDS step counters for (M - 1) / 2 chain steps, see twisted_factor */
 inline int planner_max_batch() { return QP_MAX_NB; }
 #define SFC_MAXS 512           /* sfc_kernel: max samples per axis (world extent / box resolution + 3); checked at session create */
 #define SFC_MASK_WORDS 8192    /* occupancy bitmask of a grid: 262144 cells = 32 KB; larger grids are read as floats */
