@@ -47,10 +47,12 @@ constexpr double JQ_MU0 = 3e-1, JQ_SFLOOR = 1e-1, JQ_DREG = 1e-9, JQ_STEP_FRAC =
 
 // per-mission state record (doubles)
 enum { ST_STATE = 0 /* 0 running, 1 converged, 2 failed */, ST_ITER, ST_PAR /* which (s, z) pair is current */, ST_RETRY, ST_MU, ST_GAP, ST_PRES,
-       ST_DRES, ST_SIGMU, ST_ALPHA, ST_APPLIED, ST_BT, ST_NROWS, ST_KKT, ST_FLOPS, ST_REASON, ST_AAFF, ST_POLISHED, ST_N = 32 };
+       ST_DRES, ST_SIGMU, ST_ALPHA, ST_APPLIED, ST_BT, ST_NROWS, ST_KKT, ST_FLOPS, ST_REASON, ST_AAFF, ST_POLISHED,
+       ST_GO /* polish requested for this mission (set by the control kernel, cleared by the polish) */, ST_FINAL /* ... after convergence */,
+       ST_TRIES /* early polish attempts so far */, ST_BADPIV, ST_PSTATE /* polish: see jqp_polish.inc */, ST_RDONE, ST_N = 32 };
 // reduction slots (each [4 components][nred workgroups])
 enum { RS_BUILD = 0 /* sum0 = gap, vmax = pres */, RS_POST /* dmax, gmax */, RS_AFF /* vmax, sum0, sum1, sum2 */, RS_STEP /* vmax */,
-       RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_OBJ, RS_NSLOT };
+       RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_VERIFY /* polish: worst violation at the trial point */, RS_NSLOT };
 
 struct JDims {
     int N, M, oq, nj, nk, nkp, nblk, npair, nch, ncp;
@@ -107,6 +109,10 @@ __device__ __forceinline__ Ws carve(const JArgs& A, int mission) {
     return w;
 }
 __device__ __forceinline__ double* red_slot(const Ws& w, const JLayout& L, int slot, int comp) { return w.red + ((size_t)slot * 4 + comp) * L.nred; }
+
+#define JQ_POLISH_PART 1
+#include "jqp_polish.inc"
+#undef JQ_POLISH_PART
 
 // ------------------------------------------------------------------------------------------------------------------------
 // setup: mission constants (qp.hip mission_constants), SFC box per (agent, segment) (rbp_planner.hpp:447-453), pinned end control
@@ -274,11 +280,15 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     const Ws w = carve(A, mission);
     __shared__ double red[8];
     if (w.st[ST_STATE] != 0.0) return;
-    if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0) return;
+    if (PASS == PASS_CAND || PASS == PASS_VERIFY) {
+        if (w.st[ST_GO] == 0.0 || w.st[ST_PSTATE] != (double)(PASS == PASS_CAND ? PS_SOLVE : PS_PRIMAL)) return;
+    } else if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0)
+        return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
     const int oq = d.oq, ncp = d.ncp;
     const int a = blockIdx.x / d.nch, ch = blockIdx.x % d.nch;
+    const Pol pol = pol_carve(A, mission);
     const int par = (int)w.st[ST_PAR];
     const double *bs = w.bs[par], *bz = w.bz[par], *ps = w.ps[par], *pz = w.pz[par];
     double *bs2 = w.bs[par ^ 1], *bz2 = w.bz[par ^ 1], *ps2 = w.ps[par ^ 1], *pz2 = w.pz[par ^ 1];
@@ -290,8 +300,9 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     constexpr bool aff = (PASS == PASS_AFF);
     constexpr bool accum = build || aff;
     constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
-    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD);
-    constexpr bool rd_sz = PASS != PASS_INIT;
+    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_VERIFY);
+    constexpr bool rd_sz = PASS != PASS_INIT && PASS != PASS_VERIFY;
+    constexpr bool polish = (PASS == PASS_CAND || PASS == PASS_VERIFY);
     constexpr bool wr_sz = (PASS == PASS_INIT || PASS == PASS_UPBUILD);
     PassIO io;
     io.sigma_mu = w.st[ST_SIGMU], io.alpha = w.st[ST_ALPHA];
@@ -326,6 +337,23 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                     }
                     double wgt = 0, v = 0, zo = 0, sn = 0, zn = 0;
                     const double s = rd_sz ? bs[r] : 0.0, z = rd_sz ? bz[r] : 0.0;
+                    if (polish) {
+                        const int snap = (int)(((size_t)a * 3 + k) * oq + j6);
+                        if (PASS == PASS_CAND) {
+                            if (z > s || s < 1e-6)
+                                pol_emit(pol, (int)r, a, -1, j6, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack, snap, side == 0 ? hi : lo,
+                                         fmax(z / s, 1e-300));
+                        } else {
+                            const double snv = slack - sg * dd[k];  // slack at x + dx
+                            io.vmax = fmax(io.vmax, -snv);
+                            const int q = pol.pos[r];
+                            if (q >= 0)
+                                pol.e[q] = snv;
+                            else if (snv < -1e-11)
+                                pol_emit(pol, (int)r, a, -1, j6, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack, snap, side == 0 ? hi : lo, 1.0);
+                        }
+                        continue;
+                    }
                     row_op<PASS>(slack, sg * da[k], sg * dd[k], s, z, io, 1.0, wgt, v, zo, sn, zn);
                     if (wr_sz) bs2[r] = sn, bz2[r] = zn;
                     if (accum) {
@@ -368,6 +396,22 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
             }
             double wgt = 0, v = 0, zo = 0, sn = 0, zn = 0;
             const double s = rd_sz ? ps[r] : 0.0, z = rd_sz ? pz[r] : 0.0;
+            if (polish) {
+                if (!a_lo) continue;  // (one copy of a pair row is enough here)
+                const int rowid = (int)(6 * (size_t)ncp + r);
+                if (PASS == PASS_CAND) {
+                    if (z > s || s < 1e-6) pol_emit(pol, rowid, a, b, j6, n0, n1, n2, slack, -1, 0.0, fmax(z / s, 1e-300));
+                } else {
+                    const double snv = slack - gdb;
+                    io.vmax = fmax(io.vmax, -snv);
+                    const int q = pol.pos[rowid];
+                    if (q >= 0)
+                        pol.e[q] = snv;
+                    else if (snv < -1e-11)
+                        pol_emit(pol, rowid, a, b, j6, n0, n1, n2, slack, -1, 0.0, 1.0);
+                }
+                continue;
+            }
             row_op<PASS>(slack, gab, gdb, s, z, io, a_lo ? 1.0 : 0.0, wgt, v, zo, sn, zn);
             if (wr_sz && a_lo) ps2[r] = sn, pz2[r] = zn;
             if (accum) {
@@ -418,6 +462,9 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     } else if (PASS == PASS_STEP) {
         const double vm = block_reduce(io.vmax, 1, red);
         if (tid == 0) red_slot(w, A.L, RS_STEP, 0)[wg] = vm;
+    } else if (PASS == PASS_VERIFY) {
+        const double vm = block_reduce(io.vmax, 1, red);
+        if (tid == 0) red_slot(w, A.L, RS_VERIFY, 0)[wg] = vm;
     }
 }
 
@@ -561,14 +608,24 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             const double dres = dmax / (1.0 + gmax), mu = gap / nrows;
             st[ST_GAP] = gap, st[ST_PRES] = pres, st[ST_DRES] = dres, st[ST_MU] = mu;
             st[ST_KKT] = fmax(pres, fmax(dres, mu));
+            // the exits of qp.hip, the third one without waiting for mu < 1e-14: the explicit inverses of this solver put a floor under
+            // the dual residual that RISES with the Newton weights (1e-9 .. 1e-7 once mu < 1e-10), so going on only loses accuracy
             const bool ok = (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
-                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-14);  // (the three exits of qp.hip)
-            if (ok)
-                st[ST_STATE] = 1.0;
-            else if (!(gap == gap) || st[ST_ITER] >= JQ_MAX_ITERS)
+                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-10);
+            const bool polish_on = S.p.polish != 0;
+            if (ok) {
+                if (polish_on)
+                    st[ST_GO] = 1.0, st[ST_FINAL] = 1.0;  // final crossover; the mission stays "running" until it has been tried
+                else
+                    st[ST_STATE] = 1.0;
+            } else if (!(gap == gap) || st[ST_ITER] >= JQ_MAX_ITERS) {
                 st[ST_STATE] = 2.0, st[ST_REASON] = 3.0;  // iteration cap (or NaN)
-            else
+            } else {
+                // early crossover (qp.hip): once the active set shows, at mu < 1e-6 and again at mu < 1e-8
+                const int tries = (int)st[ST_TRIES];
+                if (polish_on && tries < 2 && pres < 1e-6 && dres < 1e-6 && mu < (tries == 0 ? 1e-6 : 1e-8)) st[ST_GO] = 1.0, st[ST_TRIES] = tries + 1.0;
                 st[ST_ITER] += 1.0;
+            }
         }
     } else if (which == 2) {
         if (st[ST_RETRY] != 0.0) return;
@@ -627,6 +684,20 @@ __device__ __forceinline__ Chain chain_step(const JDims& d, int chain, int s, bo
 __device__ __forceinline__ double* sweep_buf(const Ws& w, const JDims& d, const JLayout& L, int chain, int jj, int which) {
     return which == 0 ? w.inv + (size_t)jj * L.nkpS * L.nkpS : w.scr + (size_t)chain * L.nkpS * L.nkpS;
 }
+
+// what a sweep kernel works on: kind 0 = the Schur complement of a knot (step s of a chain / the middle knot), kind 1 = the polish's
+// S_AA (jqp_polish.inc; order and buffers from the mission's polish record)
+struct SweepCtx {
+    bool active;
+    int nblk;
+    const double* src;  // X[(k + p0) & 1]
+    double* dst;        // X[(k + p0 + 1) & 1]
+    double* Pk;         // pivot inverse of step k
+    double* Pn;         // ... of step k + 1 (look-ahead)
+    double* Y;          // panel
+    double* bad;        // counter of non-positive pivots
+};
+__device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const JDims& d, int kind, int s, int mid, int k, int chain);
 
 // T_jj + Schur updates, written into the first sweep buffer (tiles I >= J).  One thread per 3x3 block (Ai, Bi) = ((a, k), (b, l)).
 __global__ __launch_bounds__(256) void jq_prep(JArgs A, int s, int mid) {
@@ -822,24 +893,24 @@ __device__ __forceinline__ void store_pivot_inverse(const double* Am, double* Pg
 }
 
 // first pivot of a knot (the others are inverted by the update kernel's look-ahead)
-__global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int s, int mid) {
+__global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int mid) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
-    const Chain c = chain_step(d, chain, s, mid != 0);
+    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, 0, chain);
     if (!c.active) return;
     __shared__ double Am[JT * LDA];
     __shared__ InvScratch sc;
     __shared__ int bad;
-    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (d.nblk & 1));
     if (threadIdx.x == 0) bad = 0;
-    for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = X[i];  // tile (0, 0)
+    for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = c.src[i];  // tile (0, 0)
     __syncthreads();
     inv64_lds(Am, &sc, &bad);
-    store_pivot_inverse(Am, w.P + ((size_t)chain * 2 + 0) * JTT);
-    if (bad && threadIdx.x == 0) w.st[ST_STATE] = 2.0, w.st[ST_REASON] = 2.0;  // Newton matrix not positive definite
+    store_pivot_inverse(Am, c.Pk);
+    // a non-positive pivot (the matrix is SPD in exact arithmetic) is counted, not fatal: the sweep needs no square roots, and with
+    // Newton weights of 1e9 the last interior-point iterations work at the edge of double precision
+    if (bad && threadIdx.x == 0) *c.bad += 1.0;
 }
 
 // operand fragments of a 16-row block for v_mfma_f64_16x16x4_f64 over K = 64: lane (i, g) holds rows[i][16 ch + 4 g + q], ch, q = 0..3
@@ -859,20 +930,19 @@ __device__ __forceinline__ void load_frag(const double* tile, int row0, bool tr,
 }
 
 // panel of step k: Y_J = B_Jk P for every J != k  (B_Jk = tile (J, k) below the pivot, tile (k, J)' left of it)
-__global__ __launch_bounds__(256) void jq_panel(JArgs A, int s, int mid, int k) {
+__global__ __launch_bounds__(256) void jq_panel(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y, J = blockIdx.x;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
-    const Chain c = chain_step(d, chain, s, mid != 0);
-    if (!c.active || J >= d.nblk || J == k) return;
-    const int nblk = d.nblk, p0 = nblk & 1;
-    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (k + p0) & 1);
-    const double* P = w.P + ((size_t)chain * 2 + (k & 1)) * JTT;
+    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
+    if (!c.active || J >= c.nblk || J == k) return;
+    const int nblk = c.nblk;
+    const double* X = c.src;
+    const double* P = c.Pk;
     const bool tr = J < k;
     const double* Z = X + (tr ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
-    double* Y = w.Y + ((size_t)chain * A.L.nblkS + J) * JTT;
+    double* Y = c.Y + (size_t)J * JTT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
     d4 zf[4];
     load_frag(Z, 16 * wave, tr, li, lg, zf);  // rows 16 wave .. of Z_J
@@ -893,24 +963,22 @@ __global__ __launch_bounds__(256) void jq_panel(JArgs A, int s, int mid, int k) 
 // update of step k: every tile (I, J), I >= J, of the lower triangle
 //   (k, k) <- -P        (I, k) <- Y_I        (k, J) <- Y_J'        else  B_IJ - Y_I B_Jk'
 // The last step writes -(...) = the inverse itself, with both triangles.  Look-ahead: the workgroup of tile (k+1, k+1) inverts it.
-__global__ __launch_bounds__(256) void jq_update(JArgs A, int s, int mid, int k) {
+__global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
-    const Chain c = chain_step(d, chain, s, mid != 0);
-    const int nblk = d.nblk;
+    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
+    const int nblk = c.nblk;
     if (!c.active || (int)blockIdx.x >= nblk * (nblk + 1) / 2) return;
     int I = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
     if (I * (I + 1) / 2 > (int)blockIdx.x) I--;
     if ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
     const int J = blockIdx.x - I * (I + 1) / 2;
-    const int p0 = nblk & 1;
-    const double* X = sweep_buf(w, d, A.L, chain, c.jj, (k + p0) & 1);
-    double* Xn = sweep_buf(w, d, A.L, chain, c.jj, (k + p0 + 1) & 1);
-    const double* P = w.P + ((size_t)chain * 2 + (k & 1)) * JTT;
-    const double* Yb = w.Y + (size_t)chain * A.L.nblkS * JTT;
+    const double* X = c.src;
+    double* Xn = c.dst;
+    const double* P = c.Pk;
+    const double* Yb = c.Y;
     const bool last = k == nblk - 1, look = !last && I == k + 1 && J == k + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;  // this wave's 32 x 32 quadrant
@@ -988,8 +1056,8 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int s, int mid, int k)
     if (look) {
         __syncthreads();
         inv64_lds(Am, &sc, &bad);
-        store_pivot_inverse(Am, w.P + ((size_t)chain * 2 + ((k + 1) & 1)) * JTT);
-        if (bad && tid == 0) w.st[ST_STATE] = 2.0, w.st[ST_REASON] = 2.0;
+        store_pivot_inverse(Am, c.Pn);
+        if (bad && tid == 0) *c.bad += 1.0;
     }
 }
 
@@ -1063,6 +1131,35 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
         else
             w.rhs[(size_t)jj * nkp + row] = w.wv[(size_t)jj * nkp + row] - acc;
     }
+}
+
+#define JQ_POLISH_PART 2
+#include "jqp_polish.inc"
+#undef JQ_POLISH_PART
+
+__device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const JDims& d, int kind, int s, int mid, int k, int chain) {
+    SweepCtx c;
+    c.bad = w.st + ST_BADPIV;
+    if (kind == 0) {
+        const Chain ch = chain_step(d, chain, s, mid != 0);
+        c.active = ch.active && w.st[ST_STATE] == 0.0 && w.st[ST_RETRY] == 0.0 && w.st[ST_GO] == 0.0;
+        c.nblk = d.nblk;
+        const int p0 = d.nblk & 1;
+        c.src = sweep_buf(w, d, A.L, chain, ch.jj, (k + p0) & 1);
+        c.dst = sweep_buf(w, d, A.L, chain, ch.jj, (k + p0 + 1) & 1);
+        c.Pk = w.P + ((size_t)chain * 2 + (k & 1)) * JTT, c.Pn = w.P + ((size_t)chain * 2 + ((k + 1) & 1)) * JTT;
+        c.Y = w.Y + (size_t)chain * A.L.nblkS * JTT;
+    } else {
+        const Pol p = pol_carve(A, blockIdx.z);
+        c.nblk = p.cnt[PC_NBLK];
+        c.active = chain == 0 && w.st[ST_STATE] == 0.0 && w.st[ST_GO] != 0.0 && w.st[ST_PSTATE] == (double)PS_SOLVE && !p.cnt[PC_BPPDONE] && k < c.nblk;
+        const int p0 = c.nblk & 1;
+        c.src = ((k + p0) & 1) ? p.W1 : p.W0;
+        c.dst = ((k + p0 + 1) & 1) ? p.W1 : p.W0;
+        c.Pk = p.P + (size_t)(k & 1) * JTT, c.Pn = p.P + (size_t)((k + 1) & 1) * JTT;
+        c.Y = p.Y;
+    }
+    return c;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1146,6 +1243,7 @@ JLayout jq_layout(int N, int MS) {
     L.o_Y = take((size_t)2 * d.nblk * JTT), L.o_P = take((size_t)4 * JTT);
     L.o_scr = take((size_t)2 * d.nkp * d.nkp);
     L.o_inv = take((size_t)d.nj * d.nkp * d.nkp);
+    L.o_pol = take(pol_layout(N, MS).total);
     L.stride = o;
     return L;
 }
@@ -1182,11 +1280,91 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
-        JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, sidx, mid);
+        JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid);
         for (int k = 0; k < nblk; ++k) {
-            if (nblk > 1) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, sidx, mid, k);
-            JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, sidx, mid, k);
+            if (nblk > 1) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, 0, sidx, mid, k);
+            JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
         }
+    };
+    const bool trace = getenv("RBP_JOINT_TRACE") != nullptr;
+    // ---- active-set polish of the missions whose control kernel asked for it (jqp_polish.inc); host-driven state machine, one
+    // synchronisation per stage
+    const PolLayout PL = pol_layout(N, s.M);
+    const int ncmax = pol_ncmax(N);
+    const size_t nrows_all = 6 * (size_t)dm.ncp + (size_t)dm.npair * dm.oq;
+    std::vector<int> cnt_h((size_t)K * PC_N);
+    int polish_rounds = 0;
+    (void)hipFuncSetAttribute((const void*)jp_z, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ncmax * sizeof(double)));
+    auto poll = [&]() -> bool {
+        return hipMemcpy2DAsync(state_h, sizeof(double) * ST_N, A.ws + L.o_state, L.stride * sizeof(double), sizeof(double) * ST_N, K,
+                                hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipMemcpy2DAsync(cnt_h.data(), sizeof(int) * PC_N, A.ws + L.o_pol + PL.cnt, L.stride * sizeof(double), sizeof(int) * PC_N, K,
+                                hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess;
+    };
+    auto polish = [&]() -> int {
+        for (int k = 0; k < K; ++k)
+            if (hipMemsetAsync(A.ws + (size_t)k * L.stride + L.o_pol + PL.pos, 0xFF, nrows_all * sizeof(int), st) != hipSuccess) return RBP_ERR_HIP;
+        JQ_LAUNCH(jp_begin, dim3(K), 18 * dm.nj * sizeof(double), A);
+        JQ_LAUNCH(jp_c0, dim3(npost, K), 0, A);
+        JQ_LAUNCH(jp_chain_mv, dim3((dm.nj * 9 * N + 255) / 256, K), 0, A, 0);
+        JQ_LAUNCH(jq_sweep<PASS_CAND>, dim3(nsw, K), 0, A);
+        for (int guard = 0; guard < 400; ++guard) {
+            if (!poll()) return RBP_ERR_HIP;
+            bool any_new = false, any_bpp = false, any_primal = false, any_refine = false;
+            int nc_max = 0, nblk_max = 0;
+            for (int k = 0; k < K; ++k) {
+                const double* q = state_h + (size_t)k * ST_N;
+                const int* c = cnt_h.data() + (size_t)k * PC_N;
+                if (q[ST_STATE] != 0.0 || q[ST_GO] == 0.0) continue;
+                if (q[ST_PSTATE] == (double)PS_SOLVE) {
+                    if (c[PC_NRAW] > 0)
+                        any_new = true, nc_max = std::max(nc_max, std::min(ncmax, c[PC_NCAND] + c[PC_NRAW]));
+                    else if (!c[PC_BPPDONE])
+                        any_bpp = true, nblk_max = std::max(nblk_max, c[PC_NBLK]);
+                } else if (q[ST_PSTATE] == (double)PS_PRIMAL) {
+                    any_primal = true, any_refine = any_refine || c[PC_REFINE];
+                }
+                if (trace)
+                    fprintf(stderr, "[jqp]   polish mission %d pstate %.0f ncand %d nraw %d nA %d ninf %d bppit %d done %d round %d outer %d reason %d\n", k,
+                            q[ST_PSTATE], c[PC_NCAND], c[PC_NRAW], c[PC_NA], c[PC_NINF], c[PC_BPPIT], c[PC_BPPDONE], c[PC_ROUND], c[PC_OUTER], c[PC_REASON]);
+            }
+            polish_rounds++;
+            if (any_new) {
+                JQ_LAUNCH(jp_sort, dim3((ncmax + 255) / 256, K), 0, A);
+                JQ_LAUNCH(jp_sort_fin, dim3(K), 0, A);
+                JQ_LAUNCH(jp_S, dim3((unsigned)(((size_t)nc_max * nc_max + 255) / 256), K), 0, A);
+                JQ_LAUNCH(jp_bpp, dim3(K), 0, A, 0);
+            } else if (any_bpp) {
+                if (nblk_max > 0) {
+                    JQ_LAUNCH(jp_gather, dim3(nblk_max * (nblk_max + 1) / 2, K), 0, A);
+                    JQ_LAUNCH(jq_pivot0, dim3(1, 1, K), 0, A, 1, 0, 0);
+                    for (int k = 0; k < nblk_max; ++k) {
+                        if (nblk_max > 1) JQ_LAUNCH(jq_panel, dim3(nblk_max, 1, K), 0, A, 1, 0, 0, k);
+                        JQ_LAUNCH(jq_update, dim3(nblk_max * (nblk_max + 1) / 2, 1, K), 0, A, 1, 0, 0, k);
+                    }
+                    JQ_LAUNCH(jp_z, dim3(nblk_max * 4, K), nblk_max * JT * sizeof(double), A, 0);
+                }
+                JQ_LAUNCH(jp_g, dim3((ncmax + 3) / 4, K), 0, A);
+                JQ_LAUNCH(jp_bpp, dim3(K), 0, A, 1);
+            } else if (any_primal) {
+                if (any_refine) {
+                    int nb = 0;
+                    for (int k = 0; k < K; ++k) nb = std::max(nb, cnt_h[(size_t)k * PC_N + PC_NBLK]);
+                    if (nb > 0) JQ_LAUNCH(jp_z, dim3(nb * 4, K), nb * JT * sizeof(double), A, 1);
+                }
+                JQ_LAUNCH(jp_jz, dim3(npost, K), 0, A);
+                JQ_LAUNCH(jp_chain_mv, dim3((dm.nj * 9 * N + 255) / 256, K), 0, A, 1);
+                JQ_LAUNCH(jp_dx, dim3(npost, K), 0, A);
+                JQ_LAUNCH(jq_sweep<PASS_VERIFY>, dim3(nsw, K), 0, A);
+                JQ_LAUNCH(jp_check, dim3(K), 0, A);
+            } else
+                break;
+        }
+        JQ_LAUNCH(jp_apply, dim3(nxblk, K), 0, A, 0);
+        JQ_LAUNCH(jp_apply, dim3((ncmax + 255) / 256, K), 0, A, 1);
+        JQ_LAUNCH(jp_end, dim3(K), 0, A);
+        return RBP_OK;
     };
     int iters = 0, rc = RBP_OK;
     const int max_rounds = JQ_MAX_ITERS + 48;
@@ -1203,7 +1381,19 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         }
         bool running = false;
         for (int k = 0; k < K; ++k) running = running || state_h[(size_t)k * ST_N + ST_STATE] == 0.0;
+        if (trace)
+            for (int k = 0; k < std::min(K, 4); ++k) {
+                const double* q = state_h + (size_t)k * ST_N;
+                fprintf(stderr, "[jqp] round %d mission %d state %.0f iter %.0f retry %.0f mu %.3e pres %.3e dres %.3e sigmu %.3e aaff %.3f alpha %.4f bt %.0f\n", it, k,
+                        q[ST_STATE], q[ST_ITER], q[ST_RETRY], q[ST_MU], q[ST_PRES], q[ST_DRES], q[ST_SIGMU], q[ST_AAFF], q[ST_ALPHA], q[ST_BT]);
+            }
         if (!running) break;
+        bool any_go = false;
+        for (int k = 0; k < K; ++k) any_go = any_go || (state_h[(size_t)k * ST_N + ST_STATE] == 0.0 && state_h[(size_t)k * ST_N + ST_GO] != 0.0);
+        if (any_go) {
+            if ((rc = polish()) != RBP_OK) break;
+            // (missions the polish has finished are skipped by the kernels below; if none is left the next poll ends the loop)
+        }
         iters++;
         JQ_LAUNCH(jq_count, dim3(K), 0, A);
         for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
@@ -1220,7 +1410,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
     }
     JQ_LAUNCH(jq_finish, dim3(K), 0, A);
-    if (stats) stats->rounds = iters;
+    if (stats) stats->rounds = iters, stats->polish_rounds = polish_rounds;
     (void)hipHostFree(state_h);
     if (hipGetLastError() != hipSuccess) rc = RBP_ERR_HIP;
     return rc;
