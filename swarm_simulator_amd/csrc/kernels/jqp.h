@@ -17,6 +17,11 @@ struct JArgs {
     DevSession S;
     double* ws;
     JLayout L;
+    int ref_step;   // which refinement step of a Newton solve the launch belongs to (kernels of step r skip missions with ST_NREF <= r)
+    int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
+    int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
+    double dreg_scale, dreg_max;
+    double tune[5];  // mu0, slack floor, centring exponent, neighbourhood gamma, step fraction
 };
 
 struct JointStats {

@@ -49,7 +49,7 @@ constexpr double JQ_MU0 = 3e-1, JQ_SFLOOR = 1e-1, JQ_DREG = 1e-9, JQ_STEP_FRAC =
 enum { ST_STATE = 0 /* 0 running, 1 converged, 2 failed */, ST_ITER, ST_PAR /* which (s, z) pair is current */, ST_RETRY, ST_MU, ST_GAP, ST_PRES,
        ST_DRES, ST_SIGMU, ST_ALPHA, ST_APPLIED, ST_BT, ST_NROWS, ST_KKT, ST_FLOPS, ST_REASON, ST_AAFF, ST_POLISHED,
        ST_GO /* polish requested for this mission (set by the control kernel, cleared by the polish) */, ST_FINAL /* ... after convergence */,
-       ST_TRIES /* early polish attempts so far */, ST_BADPIV, ST_PSTATE /* polish: see jqp_polish.inc */, ST_RDONE, ST_N = 32 };
+       ST_TRIES /* early polish attempts so far */, ST_NREF /* refinement steps per Newton solve in this iteration */, ST_BADPIV, ST_DREG /* dual regularisation of this iteration's Newton system */, ST_DREGN /* ... of the next */, ST_PSTATE /* polish: see jqp_polish.inc */, ST_RDONE, ST_N = 32 };
 // reduction slots (each [4 components][nred workgroups])
 enum { RS_BUILD = 0 /* sum0 = gap, vmax = pres */, RS_POST /* dmax, gmax */, RS_AFF /* vmax, sum0, sum1, sum2 */, RS_STEP /* vmax */,
        RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_VERIFY /* polish: worst violation at the trial point */, RS_NSLOT };
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void jq_setup(JArgs A) {
         for (int i = 0; i < ST_N; ++i) w.st[i] = 0.0;
         w.st[ST_STATE] = S.status[mission] != 0 ? 2.0 : 0.0;
         w.st[ST_NROWS] = (double)((size_t)(d.oq - 6) * (6 * (size_t)N + d.npair));
+        w.st[ST_DREG] = w.st[ST_DREGN] = A.dreg_mode == 0 ? JQ_DREG : fmin(A.dreg_max, fmax(JQ_DREG, A.dreg_scale * JQ_MU0));
     }
     __syncthreads();
     for (int m = tid; m < M; m += 256) w.segsc[m] = pow(T[m + 1] - T[m], -5.0);
@@ -210,10 +211,11 @@ __global__ __launch_bounds__(256) void jq_setup(JArgs A) {
 //   pair  (lo < hi, j6):     n . x_lo - n . x_hi <= -(r_lo + r_hi)   :668-679
 // Control points j6 < 3 and j6 >= 6M - 3 are pinned: their rows are constants, checked once (PASS_INIT) against 1e-6.
 // ------------------------------------------------------------------------------------------------------------------------
-enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_STEP, PASS_UPBUILD, PASS_CAND, PASS_VERIFY };
+enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_STEP, PASS_UPBUILD, PASS_CAND, PASS_VERIFY,
+       PASS_KMUL_A /* J'W J dxa for the iterative refinement of a Newton solve */, PASS_KMUL_D /* ... of dx */ };
 
 struct PassIO {
-    double sigma_mu, alpha;
+    double sigma_mu, alpha, dreg, dregn, mu0, sfloor;
     double sum0, sum1, sum2, vmax, vmin;
 };
 
@@ -222,11 +224,11 @@ template <int PASS>
 __device__ __forceinline__ void row_op(double slack, double ga, double gd, double s, double z, PassIO& io, double cw, double& wgt, double& v,
                                        double& zo, double& sn_out, double& zn_out) {
     if (PASS == PASS_INIT) {
-        const double s0 = slack < JQ_SFLOOR ? JQ_SFLOOR : slack;
-        sn_out = s0, zn_out = JQ_MU0 / s0;
+        const double s0 = slack < io.sfloor ? io.sfloor : slack;
+        sn_out = s0, zn_out = io.mu0 / s0;
     } else if (PASS == PASS_BUILD) {
         const double rg = s - slack;
-        wgt = z * fast_rcp(s + JQ_DREG * z);
+        wgt = z * fast_rcp(s + io.dregn * z);
         v = -wgt * (rg - s);
         zo = z;
         io.sum0 += cw * s * z;
@@ -234,7 +236,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
     } else if (PASS == PASS_AFF) {
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
-        wgt = z * fast_rcp(s + JQ_DREG * z);
+        wgt = z * fast_rcp(s + io.dreg * z);
         const double dza = wgt * (ga + rg - s);
         const double dsa = -s - s * dza * iz;
         const double cc = dsa * dza;
@@ -245,7 +247,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
     } else if (PASS == PASS_STEP) {
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
-        wgt = z * fast_rcp(s + JQ_DREG * z);
+        wgt = z * fast_rcp(s + io.dreg * z);
         const double dza = wgt * (ga + rg - s);
         const double cc = (-s - s * dza * iz) * dza;
         const double rcc = s * z + cc - io.sigma_mu;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
     } else if (PASS == PASS_UPBUILD) {
         const double rg = s - (slack + io.alpha * gd);  // the old point: slack_old = slack + alpha * gd
         const double iz = fast_rcp(z);
-        const double w0 = z * fast_rcp(s + JQ_DREG * z);
+        const double w0 = z * fast_rcp(s + io.dreg * z);
         const double dza = w0 * (ga + rg - s);
         const double cc = (-s - s * dza * iz) * dza;
         const double rcc = s * z + cc - io.sigma_mu;
@@ -265,11 +267,14 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
         sn_out = sn, zn_out = zn;
         io.vmin = fmin(io.vmin, sn * zn);
         const double rgn = sn - slack;
-        wgt = zn * fast_rcp(sn + JQ_DREG * zn);
+        wgt = zn * fast_rcp(sn + io.dregn * zn);
         v = -wgt * (rgn - sn);
         zo = zn;
         io.sum0 += cw * sn * zn;
         io.vmax = fmax(io.vmax, fabs(rgn));
+    } else if (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D) {
+        wgt = z * fast_rcp(s + io.dreg * z);  // the weight this iteration's Newton matrix was assembled with
+        v = wgt * gd;
     }
 }
 
@@ -284,6 +289,8 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
         if (w.st[ST_GO] == 0.0 || w.st[ST_PSTATE] != (double)(PASS == PASS_CAND ? PS_SOLVE : PS_PRIMAL)) return;
     } else if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0)
         return;
+    constexpr bool kmul = (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D);
+    if (kmul && w.st[ST_NREF] <= (double)A.ref_step) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
     const int oq = d.oq, ncp = d.ncp;
@@ -298,14 +305,15 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     const double* radius = S.radius + (size_t)mission * N;
     constexpr bool build = (PASS == PASS_BUILD || PASS == PASS_UPBUILD);
     constexpr bool aff = (PASS == PASS_AFF);
-    constexpr bool accum = build || aff;
+    constexpr bool accum = build || aff || kmul;
     constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
-    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_VERIFY);
+    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_VERIFY || kmul);
     constexpr bool rd_sz = PASS != PASS_INIT && PASS != PASS_VERIFY;
     constexpr bool polish = (PASS == PASS_CAND || PASS == PASS_VERIFY);
     constexpr bool wr_sz = (PASS == PASS_INIT || PASS == PASS_UPBUILD);
     PassIO io;
-    io.sigma_mu = w.st[ST_SIGMU], io.alpha = w.st[ST_ALPHA];
+    io.sigma_mu = w.st[ST_SIGMU], io.alpha = w.st[ST_ALPHA], io.dreg = w.st[ST_DREG], io.dregn = w.st[ST_DREGN];
+    io.mu0 = A.tune[0], io.sfloor = A.tune[1];
     io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 0, io.vmin = 1e300;
     double pin_viol = 0;
     const double ra = radius[a];
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
         for (int k = 0; k < 3; ++k) {
             xa[k] = ctrl[((size_t)a * 3 + k) * oq + j6];
             da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
-            dd[k] = need_dd ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = need_dd ? (PASS == PASS_KMUL_A ? w.dxa : w.dx)[((size_t)a * 3 + k) * oq + j6] : 0.0;
         }
         double Sm[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
         if (ch == 0) {  // bound rows
@@ -360,6 +368,8 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                         const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);
                         if (build) {
                             Sm[dg] += wgt, gz[k] += sg * zo, yv[k] += sg * v;
+                        } else if (kmul) {
+                            Sm[k] += sg * v;
                         } else {
                             Sm[k] += sg * v, Sm[3 + k] += sg * wgt;
                         }
@@ -390,8 +400,8 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                 gab = a_lo ? n0 * (da[0] - f0) + n1 * (da[1] - f1) + n2 * (da[2] - f2) : n0 * (f0 - da[0]) + n1 * (f1 - da[1]) + n2 * (f2 - da[2]);
             }
             if (need_dd) {
-                const double f0 = w.dx[((size_t)b * 3 + 0) * oq + j6], f1 = w.dx[((size_t)b * 3 + 1) * oq + j6],
-                             f2 = w.dx[((size_t)b * 3 + 2) * oq + j6];
+                const double* dxp = PASS == PASS_KMUL_A ? w.dxa : w.dx;
+                const double f0 = dxp[((size_t)b * 3 + 0) * oq + j6], f1 = dxp[((size_t)b * 3 + 1) * oq + j6], f2 = dxp[((size_t)b * 3 + 2) * oq + j6];
                 gdb = a_lo ? n0 * (dd[0] - f0) + n1 * (dd[1] - f1) + n2 * (dd[2] - f2) : n0 * (f0 - dd[0]) + n1 * (f1 - dd[1]) + n2 * (f2 - dd[2]);
             }
             double wgt = 0, v = 0, zo = 0, sn = 0, zn = 0;
@@ -423,6 +433,9 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                     const double zz = sg * zo, vv = sg * v;
                     gz[0] += zz * n0, gz[1] += zz * n1, gz[2] += zz * n2;
                     yv[0] += vv * n0, yv[1] += vv * n1, yv[2] += vv * n2;
+                } else if (kmul) {
+                    const double vv = sg * v;
+                    Sm[0] += vv * n0, Sm[1] += vv * n1, Sm[2] += vv * n2;
                 } else {
                     const double vv = sg * v, ww = sg * wgt;
                     Sm[0] += vv * n0, Sm[1] += vv * n1, Sm[2] += vv * n2;
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
         if (accum && !pinned) {
             double* acc = w.acc + (size_t)ch * 12 * ncp + (size_t)a * oq + j6;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) acc[(size_t)e * ncp] = Sm[e];
+            for (int e = 0; e < (kmul ? 3 : 6); ++e) acc[(size_t)e * ncp] = Sm[e];
             if (build) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) acc[(size_t)(6 + e) * ncp] = yv[e], acc[(size_t)(9 + e) * ncp] = gz[e];
@@ -571,6 +584,58 @@ __global__ __launch_bounds__(256) void jq_stepx(JArgs A) {
     ctrl[i] += (w.st[ST_ALPHA] - w.st[ST_APPLIED]) * w.dx[i];
 }
 
+// ---- iterative refinement of a Newton solve.  The substitutions multiply with explicit inverses: their residual is cond(K) eps, not eps
+// (the price of having no triangular solves), and with Newton weights of 1e9 the last interior-point iterations lose the dual residual
+// without it.  K du is formed matrix-free: K0 F du from the jerk Gram matrices, J'W J F du by a row sweep (PASS_KMUL).
+// op 0: rhs0 <- rhs (before the first solve)
+// op 1: after the KMUL sweep of refinement step `rs`: dusave <- du (rs == 0) ;  rhs <- rhs0 - K du
+// op 2: after the correction solve: rhs <- dusave + rhs ; dusave <- that
+__global__ __launch_bounds__(256) void jq_refine(JArgs A, int op, int which) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_NREF] <= (double)(op == 0 ? 0 : A.ref_step)) return;
+    const int N = S.N, M = S.Mk[mission];
+    const JDims d = jdims(N, M);
+    const int oq = d.oq, nu = 3 * N, it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= d.nj * nu) return;
+    const int j = it / nu + 1, u = it % nu, a = u / 3, k = u % 3;
+    const size_t o0 = (size_t)(j - 1) * d.nkp + u * 3;
+    double* rhs0 = w.wv + (size_t)A.L.njS * A.L.nkpS;      // [nj * nkp] behind wv
+    double* dusave = rhs0 + (size_t)A.L.njS * A.L.nkpS;
+    if (op == 0) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) rhs0[o0 + e] = w.rhs[o0 + e];
+        return;
+    }
+    if (op == 2) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const double v = dusave[o0 + e] + w.rhs[o0 + e];
+            w.rhs[o0 + e] = v, dusave[o0 + e] = v;
+        }
+        return;
+    }
+    const double* dxp = (which ? w.dx : w.dxa) + ((size_t)a * 3 + k) * oq;
+    const double* L = w.Lk + 9 * j;
+    double g[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int j6 = 6 * (j - 1) + 3 + q, m = j6 / 6, i = j6 % 6;
+        double gv = 0;
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) gv += jc_Qbase[6 * i + jj] * dxp[6 * m + jj];
+        g[q] = 2 * w.segsc[m] * gv + acc_sum(w, d, k, (size_t)a * oq + j6);
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const double kdu = g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
+        if (A.ref_step == 0) dusave[o0 + e] = w.rhs[o0 + e];
+        w.rhs[o0 + e] = rhs0[o0 + e] - kdu;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // control kernels: one workgroup per mission finishes the reductions and takes the decisions of the interior-point loop
 // ------------------------------------------------------------------------------------------------------------------------
@@ -607,6 +672,10 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
         if (tid == 0) {
             const double dres = dmax / (1.0 + gmax), mu = gap / nrows;
             st[ST_GAP] = gap, st[ST_PRES] = pres, st[ST_DRES] = dres, st[ST_MU] = mu;
+            // dual (proximal) regularisation: the weights of this iteration's Newton matrix were built with DREGN by the last sweep
+            st[ST_NREF] = mu < 1e-8 ? 2.0 : (mu < 1e-5 ? 1.0 : 0.0);
+            st[ST_DREG] = st[ST_DREGN];
+            st[ST_DREGN] = A.dreg_mode == 0 ? JQ_DREG : fmin(A.dreg_max, fmax(JQ_DREG, A.dreg_scale * mu));
             st[ST_KKT] = fmax(pres, fmax(dres, mu));
             // the exits of qp.hip, the third one without waiting for mu < 1e-14: the explicit inverses of this solver put a floor under
             // the dual residual that RISES with the Newton weights (1e-9 .. 1e-7 once mu < 1e-10), so going on only loses accuracy
@@ -636,20 +705,19 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
         if (tid == 0) {
             const double a_aff = 1.0 / vm, mu = st[ST_MU];
             const double mu_aff = (q0 + a_aff * q1 + a_aff * a_aff * q2) / nrows;
-            double sigma = mu_aff / mu;
-            sigma = sigma * sigma * sigma;
+            double sigma = pow(mu_aff / mu, A.tune[2]);
             st[ST_SIGMU] = sigma * mu, st[ST_AAFF] = a_aff;
         }
     } else if (which == 3) {
         if (st[ST_RETRY] != 0.0) return;
-        const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, JQ_STEP_FRAC, red);
-        if (tid == 0) st[ST_ALPHA] = JQ_STEP_FRAC / vm, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
+        const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, A.tune[4], red);
+        if (tid == 0) st[ST_ALPHA] = A.tune[4] / vm, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
     } else if (which == 4) {
         const double gap = red_final(red_slot(w, A.L, RS_BUILD, 0), nsw, 0, 0.0, red);
         const double pres = red_final(red_slot(w, A.L, RS_BUILD, 1), nsw, 1, 0.0, red);
         const double pmin = red_final(red_slot(w, A.L, RS_UP, 0), nsw, 2, 1e300, red);
         if (tid == 0) {
-            if (pmin >= JQ_NBHD_GAMMA * gap / nrows || st[ST_BT] >= 40.0 || !(gap == gap)) {
+            if (pmin >= A.tune[3] * gap / nrows || st[ST_BT] >= 40.0 || !(gap == gap)) {
                 st[ST_PAR] = 1.0 - st[ST_PAR], st[ST_RETRY] = 0.0, st[ST_GAP] = gap, st[ST_PRES] = pres;
             } else {  // wide-neighbourhood test failed: repeat the update sweep from the (untouched) old state with 0.8 alpha
                 st[ST_APPLIED] = st[ST_ALPHA], st[ST_ALPHA] *= 0.8, st[ST_RETRY] = 1.0, st[ST_BT] += 1.0;
@@ -802,51 +870,65 @@ __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 struct InvScratch {
-    double Pi[16 * 18];
+    double Pi[4][16 * 18];  // per wave: its copy of the diagonal sub-tile, inverted in place
     double Yb[4][16 * 18];
     double Zb[4][16 * 18];
 };
+#define JQ_WSYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+// 16 x 16 Gauss-Jordan inverse in LDS by ONE wave, in place (leading dimension 18): lane (r = l & 15, g = l >> 4) owns the entries
+// D[r][4g .. 4g+3] in registers and publishes them after every column step; what a step needs from other lanes -- the pivot, the
+// pivot row's segment, the row's entry in the pivot column -- are same-address LDS reads (broadcasts: ~7 cycles per 8 bytes, no
+// v_readlane chains).  LDS serves a wave's operations in order, so a step's reads see the previous step's writes.
+__device__ __forceinline__ bool gj16_lds(double* D, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = D[r * 18 + 4 * g + q];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double p = D[c * 18 + c], f = D[r * 18 + c];
+        double pr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pr[q] = D[c * 18 + 4 * g + q];
+        ok = ok && (p > 0.0);
+        const double ip = fast_rcp(p), fi = f * ip;
+        if (r == c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = pr[q] * ip;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] -= fi * pr[q];
+        }
+        if (g == c / 4) v[c % 4] = r == c ? ip : -fi;
+        JQ_WSYNC();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = v[q];
+        JQ_WSYNC();
+    }
+    return ok;
+}
 __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     for (int kk = 0; kk < 4; ++kk) {
-        if (wave == 0) {  // Gauss-Jordan inverse of the 16 x 16 diagonal sub-tile: row li in lane li (lanes >= 16 carry copies)
-            double a[16];
+        // every wave inverts its own copy of the diagonal sub-tile (no barrier between the inversion and the wave's panel product)
+        double* Pi = sc->Pi[wave];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = Am[(16 * kk + li) * LDA + 16 * kk + c];
-            bool okp = true;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const double p = rl(a[c], c);
-                okp = okp && (p > 0.0);
-                const double ip = fast_rcp(p);
-                const double f = a[c];
-                double rc[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) rc[q] = rl(a[q], c) * ip;
-                if (li == c) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) a[q] = rc[q];
-                    a[c] = ip;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) a[q] -= f * rc[q];
-                    a[c] = -f * ip;
-                }
-            }
-            if (!okp && lane == 0) *bad = 1;
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) sc->Pi[li * 18 + c] = a[c];
-            }
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) Pi[li * 18 + 4 * lg + q] = Am[(16 * kk + li) * LDA + 16 * kk + 4 * lg + q];
+        JQ_WSYNC();
+        const bool okp = gj16_lds(Pi, lane);
+        if (!okp && tid == 0) *bad = 1;
         // panel: row block i = wave: Z = A[i][kk] (old), Y = Z Pi'
         if (wave != kk) {
             d4 acc = d4{0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double av = Am[(16 * wave + li) * LDA + 16 * kk + 4 * q + lg];
-                const double bv = sc->Pi[li * 18 + 4 * q + lg];
+                const double bv = Pi[li * 18 + 4 * q + lg];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
             }
 #pragma unroll
@@ -861,7 +943,7 @@ __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
             double* At = Am + (16 * wave) * LDA + 16 * jb;
             if (wave == kk && jb == kk) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = -sc->Pi[(lg + 4 * r) * 18 + li];
+                for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = -Pi[(lg + 4 * r) * 18 + li];
             } else if (jb == kk) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) At[(lg + 4 * r) * LDA + li] = sc->Yb[wave][(lg + 4 * r) * 18 + li];
@@ -1073,6 +1155,7 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
     const JDims d = jdims(S.N, S.Mk[mission]);
     const Chain c = chain_step(d, chain, s, mode == 1);
     if (!c.active || (int)blockIdx.x * 16 >= d.nkp) return;
+    if (w.st[ST_NREF] < (double)A.ref_gate) return;  // a refinement pass this mission did not ask for
     const int jj = c.jj, nkp = d.nkp, nk = d.nk, nblk = d.nblk;
     extern __shared__ double vsh[];  // nkp
     const double* rj = w.rhs + (size_t)jj * nkp;
@@ -1234,7 +1317,7 @@ JLayout jq_layout(int N, int MS) {
     L.o_segsc = take(MS), L.o_Lk = take(9 * (MS + 1)), L.o_Dk = take(9 * (MS + 1)), L.o_Ek = take(9 * (MS + 1));
     L.o_boxlo = take((size_t)N * MS * 3), L.o_boxhi = take((size_t)N * MS * 3);
     L.o_dxa = take(3 * ncp), L.o_dx = take(3 * ncp);
-    L.o_rbase = take((size_t)d.nj * d.nkp), L.o_rhs = take((size_t)d.nj * d.nkp), L.o_wv = take((size_t)d.nj * d.nkp);
+    L.o_rbase = take((size_t)d.nj * d.nkp), L.o_rhs = take((size_t)d.nj * d.nkp), L.o_wv = take(3 * (size_t)d.nj * d.nkp);  // wv, then rhs0 and dusave of the iterative refinement
     L.o_red = take((size_t)RS_NSLOT * 4 * L.nred);
     L.zero_doubles = o;  // everything up to here is cleared at the start of a run
     for (int p = 0; p < 2; ++p) L.o_bs[p] = take(6 * ncp), L.o_bz[p] = take(6 * ncp), L.o_ps[p] = take(nrow), L.o_pz[p] = take(nrow);
@@ -1257,6 +1340,14 @@ size_t joint_workspace_bytes(int N, int MS) { return jq_layout(N, MS).stride * s
 int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats) {
     JArgs A;
     A.S = s, A.ws = (double*)ws, A.L = jq_layout(s.N, s.M);
+    {
+        const char* e = getenv("RBP_JQ_DREG");  // experiments: "mode,scale,max"
+        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0;
+        if (e) sscanf(e, "%d,%lf,%lf", &A.dreg_mode, &A.dreg_scale, &A.dreg_max);
+        A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
+        const char* t = getenv("RBP_JQ_TUNE");  // experiments: "mu0,sfloor,sigma exponent,neighbourhood gamma,step fraction"
+        if (t) sscanf(t, "%lf,%lf,%lf,%lf,%lf", &A.tune[0], &A.tune[1], &A.tune[2], &A.tune[3], &A.tune[4]);
+    }
     const JLayout& L = A.L;
     const int K = s.K, N = s.N;
     const JDims dm = jdims(N, s.M);  // the session's largest mission
@@ -1271,11 +1362,30 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     std::vector<double> state((size_t)K);
     double* state_h = nullptr;
     if (hipHostMalloc((void**)&state_h, sizeof(double) * K * ST_N) != hipSuccess) return RBP_ERR_HIP;
-    auto solve = [&](int which_out) {
+    int nref_round = 0;  // refinement steps per solve in this round (the largest any mission asked for; the kernels gate per mission)
+    auto substitute = [&](int which_out) {
         for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 0, sidx);
         JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 1, 0);
         for (int sidx = steps - 1; sidx >= 0; --sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 2, sidx);
+    };
+    auto solve = [&](int which_out) {
+        if (nref_round > 0) JQ_LAUNCH(jq_refine, dim3(npost, K), 0, A, 0, which_out);
+        substitute(which_out);
         JQ_LAUNCH(jq_apply_F, dim3(npost, K), 0, A, which_out);
+        for (int rs = 0; rs < nref_round; ++rs) {
+            A.ref_step = rs;
+            if (which_out == 0)
+                JQ_LAUNCH(jq_sweep<PASS_KMUL_A>, dim3(nsw, K), 0, A);
+            else
+                JQ_LAUNCH(jq_sweep<PASS_KMUL_D>, dim3(nsw, K), 0, A);
+            JQ_LAUNCH(jq_refine, dim3(npost, K), 0, A, 1, which_out);
+            A.ref_gate = rs + 1;
+            substitute(which_out);
+            A.ref_gate = 0;
+            JQ_LAUNCH(jq_refine, dim3(npost, K), 0, A, 2, which_out);
+            JQ_LAUNCH(jq_apply_F, dim3(npost, K), 0, A, which_out);
+        }
+        A.ref_step = 0;
     };
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
@@ -1337,13 +1447,17 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                 JQ_LAUNCH(jp_bpp, dim3(K), 0, A, 0);
             } else if (any_bpp) {
                 if (nblk_max > 0) {
-                    JQ_LAUNCH(jp_gather, dim3(nblk_max * (nblk_max + 1) / 2, K), 0, A);
+                    JQ_LAUNCH(jp_gather, dim3(nblk_max * nblk_max, K), 0, A);
                     JQ_LAUNCH(jq_pivot0, dim3(1, 1, K), 0, A, 1, 0, 0);
                     for (int k = 0; k < nblk_max; ++k) {
                         if (nblk_max > 1) JQ_LAUNCH(jq_panel, dim3(nblk_max, 1, K), 0, A, 1, 0, 0, k);
                         JQ_LAUNCH(jq_update, dim3(nblk_max * (nblk_max + 1) / 2, 1, K), 0, A, 1, 0, 0, k);
                     }
                     JQ_LAUNCH(jp_z, dim3(nblk_max * 4, K), nblk_max * JT * sizeof(double), A, 0);
+                    for (int rr = 0; rr < 2; ++rr) {  // two refinement steps: the multipliers' signs drive the exchange
+                        JQ_LAUNCH(jp_z, dim3(nblk_max * 4, K), nblk_max * JT * sizeof(double), A, 1);
+                        JQ_LAUNCH(jp_z, dim3(nblk_max * 4, K), nblk_max * JT * sizeof(double), A, 2);
+                    }
                 }
                 JQ_LAUNCH(jp_g, dim3((ncmax + 3) / 4, K), 0, A);
                 JQ_LAUNCH(jp_bpp, dim3(K), 0, A, 1);
@@ -1351,7 +1465,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                 if (any_refine) {
                     int nb = 0;
                     for (int k = 0; k < K; ++k) nb = std::max(nb, cnt_h[(size_t)k * PC_N + PC_NBLK]);
-                    if (nb > 0) JQ_LAUNCH(jp_z, dim3(nb * 4, K), nb * JT * sizeof(double), A, 1);
+                    if (nb > 0) JQ_LAUNCH(jp_z, dim3(nb * 4, K), nb * JT * sizeof(double), A, 3);
                 }
                 JQ_LAUNCH(jp_jz, dim3(npost, K), 0, A);
                 JQ_LAUNCH(jp_chain_mv, dim3((dm.nj * 9 * N + 255) / 256, K), 0, A, 1);
@@ -1388,6 +1502,9 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                         q[ST_STATE], q[ST_ITER], q[ST_RETRY], q[ST_MU], q[ST_PRES], q[ST_DRES], q[ST_SIGMU], q[ST_AAFF], q[ST_ALPHA], q[ST_BT]);
             }
         if (!running) break;
+        nref_round = 0;
+        for (int k = 0; k < K; ++k)
+            if (state_h[(size_t)k * ST_N + ST_STATE] == 0.0) nref_round = std::max(nref_round, (int)state_h[(size_t)k * ST_N + ST_NREF]);
         bool any_go = false;
         for (int k = 0; k < K; ++k) any_go = any_go || (state_h[(size_t)k * ST_N + ST_STATE] == 0.0 && state_h[(size_t)k * ST_N + ST_GO] != 0.0);
         if (any_go) {

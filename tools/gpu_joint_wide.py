@@ -13,8 +13,9 @@ n = int(args[0]) if len(args) > 0 else 16
 mid = int(args[1]) if len(args) > 1 else 3
 reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 2
 p = Param.test_sweep(sequential=False)
-if n == 256:
-    m = host.load_mission("mission_256agents_synth.json")
+if n == 256:  # BASELINE config C4 (tools/make_mission_256.py): the world is x in [-5, 15]
+    p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
+    m = host.load_mission("mission_256agents_c4.json")
 else:
     m = host.load_mission(f"mission_{n}agents_15.json")
 w = host.load_world(f"map{mid}.bt", p)
