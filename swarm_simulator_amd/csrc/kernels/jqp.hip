@@ -677,10 +677,11 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             st[ST_DREG] = st[ST_DREGN];
             st[ST_DREGN] = A.dreg_mode == 0 ? JQ_DREG : fmin(A.dreg_max, fmax(JQ_DREG, A.dreg_scale * mu));
             st[ST_KKT] = fmax(pres, fmax(dres, mu));
-            // the exits of qp.hip, the third one without waiting for mu < 1e-14: the explicit inverses of this solver put a floor under
-            // the dual residual that RISES with the Newton weights (1e-9 .. 1e-7 once mu < 1e-10), so going on only loses accuracy
+            // the exits of qp.hip, the third one at mu < 1e-9 instead of 1e-14: the explicit inverses of this solver put a floor under the
+            // dual residual that RISES with the Newton weights (1e-9 .. 1e-5 once mu < 1e-10, even with two refinement steps per solve),
+            // so going on only loses accuracy; what turns this iterate into the optimum is the active-set polish, not more iterations
             const bool ok = (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
-                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-10);
+                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-9);
             const bool polish_on = S.p.polish != 0;
             if (ok) {
                 if (polish_on)
@@ -1279,6 +1280,7 @@ __global__ __launch_bounds__(256) void jq_finish(JArgs A) {
         scal[SC_IPM_ITERS] += w.st[ST_ITER];
         scal[SC_QP_SOLVED] += 1;
         scal[SC_POLISHED] += w.st[ST_POLISHED];
+        if (w.st[ST_POLISHED] == 0.0) scal[SC_PROF0] = w.st[ST_REASON];  // why the polish was refused (100 + jqp_polish.inc reason)
         scal[SC_KKT_MAX] = fmax(scal[SC_KKT_MAX], w.st[ST_KKT]);
         scal[SC_FLOPS] += w.st[ST_FLOPS];
         scal[SC_ROWS] += w.st[ST_NROWS] * (1.0 + 4.0 * w.st[ST_ITER]);

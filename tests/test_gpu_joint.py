@@ -1,0 +1,123 @@
+"""The grid-wide JOINT QP (plan/sequential = false, the reference's code default: param.hpp:67, rbp_planner.hpp:857-859; kernels/jqp.hip).
+Needs an MI355X.
+
+* 8 / 16 agents: grid-wide solver == one-workgroup solver == oracle within CTRL_TOL (three solvers, two of them sharing no linear
+  algebra: tile-sweep inverses + block principal pivoting here, LDL' chains + Lawson-Hanson in kernels/qp.hip);
+* 32 / 64 agents: against the committed oracle vectors tests/golden/joint32_map7.npz / joint64_map3.npz (the oracle needs 26 s / 300 s
+  on one core: tests/golden/make_joint_golden.py); 64 agents additionally certified by the independent numpy restatement on a sub-block
+  of the QP (rows and variables of eight agents, everything else fixed at the answer);
+* 256 agents (BASELINE config C4's mission, joint): solved, every constraint set of the reference satisfied;
+* sessions: several joint missions in one session == the one-mission calls bit for bit; a second run of a session repeats the first.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CTRL_TOL = 2e-6
+FEAS_TOL = 1e-8
+EQ_TOL = 5e-8
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _inputs(n, map_id, **pkw):
+    p = Param.test_sweep(sequential=False, **pkw)
+    m = host.load_mission(f"mission_{n}agents_15.json")
+    w = host.load_world(f"map{map_id}.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    return p, m, w, init
+
+
+def _plan(p, m, w, init, wide, monkeypatch):
+    monkeypatch.setenv("RBP_JOINT_WIDE", "1" if wide else "0")
+    g = init.clone_inputs()
+    assert planner.Corridor(w, m, p).update(False, g)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, g), pl.last_error
+    return g
+
+
+@pytest.mark.parametrize("n,map_id", [(8, 5), (16, 3)])
+def test_grid_wide_vs_one_workgroup_vs_oracle(n, map_id, monkeypatch):
+    p, m, w, init = _inputs(n, map_id)
+    ref = init.clone_inputs()
+    assert O.corridor_update(w, m, p, ref)[0] == 0
+    rc, rep = O.planner_update(m, p, ref)
+    assert rc == 0 and rep["n_polished"] == 1
+    wide = _plan(p, m, w, init, True, monkeypatch)
+    one = _plan(p, m, w, init, False, monkeypatch)
+    assert wide.qp_solves == 1 and wide.qp_unpolished == 0 and wide.kkt_max < 1e-9
+    for g in (wide, one):
+        assert np.abs(ref.ctrl - g.ctrl).max() < CTRL_TOL
+        assert abs(ref.total_cost - g.total_cost) <= 1e-8 * max(1.0, abs(ref.total_cost))
+        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+    assert np.abs(wide.ctrl - one.ctrl).max() < CTRL_TOL
+
+
+@pytest.mark.parametrize("n,map_id", [(32, 7), (64, 3)])
+def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
+    gold = np.load(os.path.join(GOLDEN, f"joint{n}_map{map_id}.npz"))
+    p, m, w, init = _inputs(n, map_id)
+    assert hashlib.sha256(np.ascontiguousarray(init.init_traj).tobytes()).hexdigest() == str(gold["init_traj_sha256"])
+    g = _plan(p, m, w, init, True, monkeypatch)
+    assert g.M == int(gold["M"]) and g.qp_solves == 1
+    assert g.qp_unpolished == 0 and g.kkt_max < 1e-9
+    assert np.abs(gold["ctrl"] - g.ctrl).max() < CTRL_TOL
+    assert abs(float(gold["total_cost"]) - g.total_cost) <= 1e-8 * max(1.0, abs(g.total_cost))
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+
+
+def test_joint_256_agents_solved_and_feasible(monkeypatch):
+    """BASELINE config C4's mission as ONE joint QP: knot blocks of order 2304 (no mission file of this size exists upstream:
+    tools/make_mission_256.py).  No oracle can follow (dense LU of order ~1e5): the reference's constraint sets judge the answer."""
+    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+    p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
+    m = host.load_mission("mission_256agents_c4.json")
+    w = host.load_world("map1.bt", p)
+    init = host.ecbs_plan(w, m, p)
+    g = init.clone_inputs()
+    assert planner.Corridor(w, m, p).update(False, g)
+    pl = planner.RBPPlanner(m, p)
+    assert pl.update(False, g), pl.last_error
+    assert g.qp_solves == 1 and (g.qp_unpolished == 0 or g.kkt_max < 1e-7)
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+    assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
+
+
+def test_joint_session_matches_one_mission_calls_and_repeats(monkeypatch):
+    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+    p = Param.test_sweep(sequential=False)
+    m = host.load_mission("mission_16agents_15.json")
+    maps = [3, 9, 4]  # (M = 34, 34, 36 on these maps: a ragged session)
+    worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+    singles = []
+    for w, init in zip(worlds, inits):
+        g = init.clone_inputs()
+        assert planner.Corridor(w, m, p).update(False, g)
+        assert planner.RBPPlanner(m, p).update(False, g)
+        singles.append(g)
+    plans = [g.clone_inputs() for g in inits]
+    sess = planner.Session(worlds, [m] * len(maps), p, plans)
+    runs = []
+    for _ in range(2):
+        sess.reset()
+        sess.run(A.RBP_STAGE_ALL)
+        assert sess.download() == [0] * len(maps)
+        runs.append([g.ctrl.copy() for g in plans])
+    sess.close()
+    for a, b, s in zip(runs[0], runs[1], singles):
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+        assert np.array_equal(a.view(np.uint64), s.ctrl.view(np.uint64))

@@ -16,7 +16,7 @@ m = host.load_mission(f"mission_{n}agents_15.json")
 worlds = [host.load_world(f"map{i}.bt", p) for i in range(first, first + count)]
 plans = [host.ecbs_plan(w, m, p) for w in worlds]
 sess = planner.Session(worlds, [m] * count, p, plans)
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     sess.reset()
     t = time.time(); sess.run(A.RBP_STAGE_ALL); st = sess.download(); dt = time.time() - t
 sc = sess.scalars(12)
@@ -24,5 +24,5 @@ print(f"{count} missions in {dt:.3f}s = {count * n / dt:.0f} agent-traj/s")
 for i, g in enumerate(plans):
     feas = O.evaluate_ctrl(m, g) if st[i] == 0 else None
     print(f"map{first + i}: status {st[i]} M {g.M} iters {g.qp_iterations} unpolished {g.qp_unpolished} kkt {g.kkt_max:.2e} cost {g.total_cost:.9f} "
-          f"reason {sc[i][9]:.0f} it {sc[i][10]:.0f} feas {feas}")
+          f"why {sc[i][8]:.0f} reason {sc[i][9]:.0f} it {sc[i][10]:.0f} feas {feas}")
 sess.close()
