@@ -300,7 +300,14 @@ def main():
         sess.reset(stream)
         sess.run(A.RBP_STAGE_ALL, stream)
 
-    for _ in range(max(args.warmup, 1)):
+    # the session's FIRST run has no history for the block order (DevSession::qp_order: longest mission of the previous run first): it
+    # is timed on its own and reported beside `value` (value_first_run) -- the reference's sweep plans every map once
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    first_run_s = time.perf_counter() - tf0
+    for _ in range(max(args.warmup, 1) - 1):
         step()
     torch.cuda.synchronize()
     status = sess.download(stream)
@@ -354,6 +361,7 @@ def main():
         except Exception:
             pass
         sfc_bytes = 4.0 * ct["sfc_samples"]
+        joint_wide = args.joint and N > 32 and os.environ.get("RBP_JOINT_WIDE", "1") != "0"
         out = {
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
@@ -369,6 +377,7 @@ def main():
                        "block_order": ("plain (RBP_QP_ORDER=0)" if os.environ.get("RBP_QP_ORDER", "1")[:1] == "0" else
                                        "longest mission of the session's previous run first (the warm-up steps supply the history; the first "
                                        "run of a session uses plain order; results do not depend on the order)")},
+            "value_first_run": K * N / first_run_s,
             "stage_ms": {"corridor": corridor_ms, "planner": planner_ms},
             "roofline": {"bound": "hbm", "kernel": "qp_batch_kernel", "achieved": qp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": qp_gbs / HBM_PEAK_GBS, "hbm_frac": qp_gbs / HBM_PEAK_GBS,
@@ -381,7 +390,11 @@ def main():
                                        "the kernel, DESIGN.md 3.3) / kernel time / 8 TB/s.  achieved is algorithmic GB/s, NOT measured "
                                        "traffic (that is `traffic`, PMC).  mfma_frac = logged block-factorisation flops / kernel time / "
                                        "78.6 TFLOP/s (SURVEY 8d); the block-tridiagonal structure is exploited, so it stays small",
-                         "algorithmic_bytes_per_launch": ct["qp_row_bytes"], "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": ct["qp_row_bytes"],
+                         # HBM-side bytes per launch of a SEPARATE rocprofv3 --pmc collection (not of this run): profiled, tied to the
+                         # kernel sources by hash; `traffic` keeps the contract's key
+                         "traffic": traffic, "traffic_profiled": traffic, "traffic_source": traffic_src,
+                         "traffic_ratio": (traffic / ct["qp_row_bytes"]) if traffic and ct["qp_row_bytes"] else None,
                          "mfma": {"achieved": qp_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS,
                                   "flops_per_launch": ct["qp_flops"]},
                          "ipm_iterations_per_step": ct["qp_ipm_iters"], "constraint_rows_swept_per_step": ct["qp_constraint_rows"],
@@ -391,6 +404,18 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s (reference-equivalent sample bytes, not physical)",
                              "frac": sfc_bytes / (corridor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "samples_per_step": ct["sfc_samples"]},
         }
+        if joint_wide:
+            # the grid-wide joint QP (kernels/jqp.hip): the dominant kernels are the rank-64 tile updates of the sweep inversion
+            # (jq_update / jq_panel, v_mfma_f64_16x16x4_f64); SURVEY 8(d)'s roof for the QP is FP64 MFMA.  achieved = the MFMA flops the
+            # solver logs (tile updates + panels of every factorisation) / planner-stage time (HIP events on the launch stream; the
+            # stage also holds sweeps, substitutions and the polish, so this is a lower bound of the kernels' own rate -- the rocprofv3
+            # summary under profiles/ has their durations)
+            out["roofline"] = {"bound": "mfma", "kernel": "jq_update + jq_panel (joint QP, kernels/jqp.hip)", "achieved": qp_tflops,
+                               "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS,
+                               "mfma_frac": qp_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "flops_per_step": ct["qp_flops"], "ipm_iterations_per_step": ct["qp_ipm_iters"],
+                               "qps_per_step": ct["qp_solves"], "qps_polished_per_step": ct["qp_polished"], "kkt_max": ct["kkt_max"]}
+            out["config"]["qp_kernel_variant"] = "grid-wide joint (jqp)"
         # the single-mission latency and the CPU baseline are rank-0, N = 1 legs (the other ranks would only wait for them)
         if world_size == 1 and N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint and not args.no_latency:
             try:
@@ -401,6 +426,10 @@ def main():
                 out["single_sweep"] = single_sweep_rate(args.agents, param)
             except Exception as e:
                 out["single_sweep"] = {"error": str(e)}
+            # top-level scalars (summaries keep top-level keys only)
+            lat, ss = out["latency_ms_single_mission"], out["single_sweep"]
+            out["single_mission_two_calls_ms"] = lat.get("two_calls_ms") if isinstance(lat, dict) else None
+            out["single_sweep_value"] = ss.get("value") if isinstance(ss, dict) else None
         if world_size == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.agents, pkw)

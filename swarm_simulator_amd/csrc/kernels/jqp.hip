@@ -42,7 +42,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int JT = 64;          // tile order
 constexpr int JTT = JT * JT;    // doubles per tile
-constexpr int JQ_MAX_ITERS = 80;
+constexpr int JQ_MAX_ITERS = 250;
 constexpr double JQ_MU0 = 3e-1, JQ_SFLOOR = 1e-1, JQ_DREG = 1e-9, JQ_STEP_FRAC = 0.997, JQ_NBHD_GAMMA = 1e-3;
 
 // per-mission state record (doubles)
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
         if (w.st[ST_GO] == 0.0 || w.st[ST_PSTATE] != (double)(PASS == PASS_CAND ? PS_SOLVE : PS_PRIMAL)) return;
     } else if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0)
         return;
+    if (PASS == PASS_UPBUILD && A.retry_only && w.st[ST_RETRY] == 0.0) return;  // (a repeat launch: only for missions whose step was refused)
     constexpr bool kmul = (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D);
     if (kmul && w.st[ST_NREF] <= (double)A.ref_step) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256) void jq_stepx(JArgs A) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || (A.retry_only && w.st[ST_RETRY] == 0.0)) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const int nx = N * 3 * 6 * M, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nx) return;
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
         const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, A.tune[4], red);
         if (tid == 0) st[ST_ALPHA] = A.tune[4] / vm, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
     } else if (which == 4) {
+        if (A.retry_only && st[ST_RETRY] == 0.0) return;
         const double gap = red_final(red_slot(w, A.L, RS_BUILD, 0), nsw, 0, 0.0, red);
         const double pres = red_final(red_slot(w, A.L, RS_BUILD, 1), nsw, 1, 0.0, red);
         const double pmin = red_final(red_slot(w, A.L, RS_UP, 0), nsw, 2, 1e300, red);
@@ -1344,7 +1346,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     A.S = s, A.ws = (double*)ws, A.L = jq_layout(s.N, s.M);
     {
         const char* e = getenv("RBP_JQ_DREG");  // experiments: "mode,scale,max"
-        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0;
+        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0;
         if (e) sscanf(e, "%d,%lf,%lf", &A.dreg_mode, &A.dreg_scale, &A.dreg_max);
         A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
         const char* t = getenv("RBP_JQ_TUNE");  // experiments: "mu0,sfloor,sigma exponent,neighbourhood gamma,step fraction"
@@ -1514,6 +1516,19 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             // (missions the polish has finished are skipped by the kernels below; if none is left the next poll ends the loop)
         }
         iters++;
+        bool all_retry = true;
+        for (int k = 0; k < K; ++k)
+            if (state_h[(size_t)k * ST_N + ST_STATE] == 0.0 && state_h[(size_t)k * ST_N + ST_RETRY] == 0.0) all_retry = false;
+        if (all_retry) {  // every running mission only repeats its update sweep
+            A.retry_only = 1;
+            for (int rep = 0; rep < 8; ++rep) {
+                JQ_LAUNCH(jq_stepx, dim3(nxblk, K), 0, A);
+                JQ_LAUNCH(jq_sweep<PASS_UPBUILD>, dim3(nsw, K), 0, A);
+                JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
+            }
+            A.retry_only = 0;
+            continue;
+        }
         JQ_LAUNCH(jq_count, dim3(K), 0, A);
         for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
         factor_knot(0, 1);
@@ -1527,6 +1542,15 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jq_stepx, dim3(nxblk, K), 0, A);
         JQ_LAUNCH(jq_sweep<PASS_UPBUILD>, dim3(nsw, K), 0, A);
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
+        // a step the wide-neighbourhood test refused is repeated with 0.8 alpha right away (three launches that do nothing for the
+        // missions whose step was accepted), not a round later: a round is ~600 launches
+        A.retry_only = 1;
+        for (int rep = 0; rep < 6; ++rep) {
+            JQ_LAUNCH(jq_stepx, dim3(nxblk, K), 0, A);
+            JQ_LAUNCH(jq_sweep<PASS_UPBUILD>, dim3(nsw, K), 0, A);
+            JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
+        }
+        A.retry_only = 0;
     }
     JQ_LAUNCH(jq_finish, dim3(K), 0, A);
     if (stats) stats->rounds = iters, stats->polish_rounds = polish_rounds;
