@@ -1156,9 +1156,14 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
-    const Chain c = chain_step(d, chain, s, mode == 1);
+    const Chain c = chain_step(d, chain, s, mode == 1 || mode == 3);
     if (!c.active || (int)blockIdx.x * 16 >= d.nkp) return;
     if (w.st[ST_NREF] < (double)A.ref_gate) return;  // a refinement pass this mission did not ask for
+    if (mode == 3) {  // x_m: wv -> rhs (the middle step cannot write rhs itself: the other slabs of its launch still read r_m there)
+        const int row = blockIdx.x * 16 + (tid >> 4);
+        if ((tid & 15) == 0 && row < d.nk) w.rhs[(size_t)c.jj * d.nkp + row] = w.wv[(size_t)c.jj * d.nkp + row];
+        return;
+    }
     const int jj = c.jj, nkp = d.nkp, nk = d.nk, nblk = d.nblk;
     extern __shared__ double vsh[];  // nkp
     const double* rj = w.rhs + (size_t)jj * nkp;
@@ -1213,7 +1218,7 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
         if (mode == 0)
             w.wv[(size_t)jj * nkp + row] = acc;
         else if (mode == 1)
-            w.rhs[(size_t)jj * nkp + row] = acc;
+            w.wv[(size_t)jj * nkp + row] = acc;  // (copied to rhs by the mode 3 launch)
         else
             w.rhs[(size_t)jj * nkp + row] = w.wv[(size_t)jj * nkp + row] - acc;
     }
@@ -1370,6 +1375,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     auto substitute = [&](int which_out) {
         for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 0, sidx);
         JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 1, 0);
+        JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 3, 0);
         for (int sidx = steps - 1; sidx >= 0; --sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 2, sidx);
     };
     auto solve = [&](int which_out) {

@@ -99,9 +99,12 @@ def test_mixed_radius_corridor_bit_exact_and_qp_vs_oracle():
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
 
 
-def test_corridor_only_session_with_a_joint_batch_wider_than_the_qp_kernel():
+def test_corridor_only_session_with_a_joint_batch_wider_than_the_qp_kernel(monkeypatch):
     """plan/sequential=false is the reference's code default (param.hpp:67): setBatch makes one batch of all N agents.  For N above
-    the QP kernel's widest batch the PLANNER stage is refused -- but Corridor::update has nothing to do with the batch width."""
+    the ONE-WORKGROUP QP kernel's widest batch the PLANNER stage of that solver is refused -- but Corridor::update has nothing to do with
+    the batch width.  (Since round 4 such a joint QP runs on the grid-wide solver, tests/test_gpu_joint.py; RBP_JOINT_WIDE=0 asks for the
+    one-workgroup kernel.)"""
+    monkeypatch.setenv("RBP_JOINT_WIDE", "0")
     p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
     m = host.load_mission("mission_256agents_c4.json")
     w = host.load_world("map1.bt", p)
