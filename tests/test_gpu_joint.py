@@ -37,6 +37,21 @@ def _inputs(n, map_id, **pkw):
     return p, m, w, init
 
 
+def _certify_sub_blocks(p, m, w, init, g, blocks, block=8):
+    """block-coordinate optimality of the joint answer, judged by the independent numpy restatement (tests/golden/make_kkt_reference.py):
+    the QP over `block` agents with every other agent frozen AT THE ANSWER (plan/sequential = true, batch_size = block, dummy = the
+    answer) must have the answer's own control points as its certified optimum -- a necessary condition of joint optimality that needs
+    neither solver."""
+    sys.path.insert(0, GOLDEN)
+    import make_kkt_reference as K
+    from swarm_simulator_amd.types import PlanResult
+    pr0 = PlanResult(init.init_traj, init.T)   # corridor times before timeScale (the oracle's corridor: bit-identical to the GPU's)
+    assert O.corridor_update(w, m, p, pr0)[0] == 0
+    assert np.array_equal(pr0.sfc_box, g.sfc_box)
+    return K.certify_plan(init.T, init.init_traj, m.start, m.goal, m.radius, g.sfc_box, pr0.sfc_time, g.sfc_count, g.rsfc_normal,
+                          pr0.rsfc_time, g.ctrl, True, block, (m.qn + block - 1) // block, only_batches=blocks, ctrl_before_pass=g.ctrl)
+
+
 def _plan(p, m, w, init, wide, monkeypatch):
     monkeypatch.setenv("RBP_JOINT_WIDE", "1" if wide else "0")
     g = init.clone_inputs()
@@ -76,6 +91,11 @@ def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
     assert abs(float(gold["total_cost"]) - g.total_cost) <= 1e-8 * max(1.0, abs(g.total_cost))
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+    if n == 64:
+        for rep in _certify_sub_blocks(p, m, w, init, g, [0, 3, 7]):
+            tag = f"agents {8 * rep['batch']}..: " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
+            assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
+            assert rep["forward_error"] < CTRL_TOL, tag
 
 
 def test_joint_256_agents_solved_and_feasible(monkeypatch):
@@ -94,6 +114,18 @@ def test_joint_256_agents_solved_and_feasible(monkeypatch):
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
     assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
+    # the numpy restatement on two sub-blocks of eight agents.  The 256-agent answer is usually NOT polished (qp_unpolished = 1: the
+    # active-set polish of kernels/jqp_polish.inc is refused on most problems of this size), i.e. it is an interior-point answer with the
+    # reported KKT residual.  Such a point is not a vertex of its active set, so the certificate's active-set reconstruction (x_as,
+    # forward_error) does not apply; what it certifies then are the KKT residuals of the point itself in the reference's variables:
+    # feasibility, stationarity with multipliers >= 0 (NNLS), complementarity
+    for rep in _certify_sub_blocks(p, m, w, init, g, [5, 20]):
+        tag = ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
+        assert rep["viol_ineq"] < 1e-8 and rep["viol_eq"] < 1e-8, tag
+        if g.qp_unpolished == 0:
+            assert rep["x_as_viol_ineq"] < 1e-7 and rep["stationarity"] < 1e-7 and rep["forward_error"] < CTRL_TOL, tag
+        else:
+            assert rep["stationarity"] < 1e-5 and rep["complementarity"] < 1e-8, tag
 
 
 def test_joint_session_matches_one_mission_calls_and_repeats(monkeypatch):
