@@ -345,3 +345,95 @@ if __name__ == "__main__":
     import json
     # mission geometry of the C1 case: start/goal come with the golden's mission file; only arrays are used here
     raise SystemExit("the C1 matrix fixture is written by tests/golden/make_golden.py --kkt (needs the mission loader)")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# timeScale (rbp_planner.hpp:209-266 with :708-847), restated with BOTH root rules, to measure the one conscious deviation of the
+# product and the oracle: roots_derivative (:727-754) inspects the first `i` eigenvalues of Eigen's companion-matrix
+# solver (`for j < i`, :747; i = 2 for the velocity test, whose companion matrix has order 3), the product uses all real roots.
+# Eigen is absent here; LAPACK's eigenvalue order (numpy.linalg.eigvals) stands in for Eigen's.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _coef_der(c):
+    """c[0..5]: descending powers of one segment (rbp_planner.hpp:708-719) -> coef_der[i][q], i = 0..3"""
+    n = 5
+    out = np.zeros((4, n + 1))
+    for i in range(4):
+        for j in range(n + 1):
+            if i <= j:
+                f = 1
+                for t in range(i):
+                    f *= (j - t)
+                out[i, n - j] = f * c[n - j]
+    return out
+
+
+def _roots_reference_rule(cd, i):
+    """roots_derivative(i, coef_der) as written (:727-754): only the first i eigenvalues are looked at"""
+    n = 5
+    n_der = n - i
+    while n_der > 0 and cd[i, n - i - n_der] == 0:
+        n_der -= 1
+    if n_der == 0:
+        return []
+    A = np.zeros((n_der, n_der))
+    for j in range(n_der):
+        if j < n_der - 1:
+            A[j + 1, j] = 1
+        A[0, j] = -cd[i, n - i - n_der + j + 1] / cd[i, n - i - n_der]
+    ev = np.linalg.eigvals(A)
+    return [float(np.real(ev[j])) for j in range(min(i, len(ev))) if np.imag(ev[j]) == 0]
+
+
+def _roots_all_real(cd, i):
+    n = 5
+    p = cd[i, :n - i + 1]
+    p = np.trim_zeros(p, "f")
+    if len(p) <= 1:
+        return []
+    return [float(np.real(r)) for r in np.roots(p) if abs(np.imag(r)) < 1e-12 * max(1.0, abs(r))]
+
+
+def time_scale_of(coef, T, max_vel, max_acc, rule):
+    """timeScale's factor (:209-233) for coef [N][3][6M] (descending powers per segment); rule: 'reference' | 'all_real'"""
+    N, _, oq = coef.shape
+    M = oq // 6
+    roots = _roots_reference_rule if rule == "reference" else _roots_all_real
+    ts_all = 1.0
+    for qi in range(N):
+        for k in range(3):
+            for m in range(M):
+                cd = _coef_der(coef[qi, k, 6 * m:6 * m + 6])
+                dt = T[m + 1] - T[m]
+                cand = roots(cd, 2) + [0.0, dt]
+                vel_max, t_max = 0.0, 0.0
+                for t in cand:
+                    if t < 0 or t > dt:
+                        continue
+                    v = abs(sum(cd[1, i] * t ** (4 - i) for i in range(5)))
+                    if vel_max < v:
+                        vel_max, t_max = v, t
+                sc = 1.0
+                while vel_max > max_vel[qi, k]:
+                    sc *= 1.1
+                    vel_max = abs(sum(cd[1, i] * (1 / sc) ** (5 - i) * t_max ** (4 - i) for i in range(5)))
+                ts_all = max(ts_all, sc)
+                a, b, c = cd[3, 0], cd[3, 1], cd[3, 2]
+                D = b * b - 4 * a * c
+                cand = [0.0, dt]
+                if D >= 0 and a != 0:
+                    cand += [(-b + np.sqrt(D)) / (2 * a), (-b - np.sqrt(D)) / (2 * a)]
+                elif a == 0 and b != 0:
+                    cand.append(-c / b)
+                acc_max, t_max = 0.0, 0.0
+                for t in cand:
+                    if t < 0 or t > dt:
+                        continue
+                    v = abs(sum(cd[2, i] * t ** (3 - i) for i in range(4)))
+                    if acc_max < v:
+                        acc_max, t_max = v, t
+                sc = 1.0
+                while acc_max > max_acc[qi, k]:
+                    sc *= 1.1
+                    acc_max = abs(sum(cd[2, i] * (1 / sc) ** (5 - i) * t_max ** (3 - i) for i in range(4)))
+                ts_all = max(ts_all, sc)
+    return ts_all

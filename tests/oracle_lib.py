@@ -141,3 +141,11 @@ def ctrl_to_coef(T, ctrl):
     coef = np.zeros_like(ctrl)
     lib().oracle_ctrl_to_coef(N, len(T) - 1, A.ptr(T, A.c_double_p), A.ptr(ctrl, A.c_double_p), A.ptr(coef, A.c_double_p))
     return coef
+
+
+def time_scale(mission: Mission, plan: PlanResult):
+    """oracle_time_scale (rbp_planner.hpp:209-266): returns the factor and rescales plan.coef / T / corridor times in place."""
+    m, pl = mission.c_struct(), plan.c_struct()
+    ts = lib().oracle_time_scale(C.byref(m), C.byref(pl))
+    plan.sync_from(pl)
+    return ts
