@@ -154,6 +154,9 @@ def cpu_baseline(n_agents, pkw, budget_s=25.0):
         # and ECBS of every worker -- stages the GPU figure excludes too -- and is kept as wall_incl_setup.
         slowest = max(r[1] for r in good) if good else float("nan")
         out["all_cores"] = {"value": sum(r[0] for r in good) / slowest, "unit": "agent-trajectories/s", "cores": workers,
+                            # an UPPER BOUND of the CPU rate, not a measurement of it: it assumes every worker's stage time overlaps
+                            # the others' perfectly (the pool staggers their starts); the measured figure is wall_incl_setup
+                            "value_is": "upper bound (perfect overlap of the workers' stage times assumed)",
                             "wall_incl_setup": sum(r[0] for r in good) / dt,
                             "sample": f"{len(good)} missions (maps 1..{min(50, n_missions)}, one per process, {workers} processes running "
                                       f"concurrently): corridor+planner of the slowest worker {slowest:.2f}s; pool wall time {dt:.1f}s "

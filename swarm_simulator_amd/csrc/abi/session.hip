@@ -490,14 +490,18 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
             if (ts != 1.0)
                 for (int m = 0; m < Mq; ++m) p.rsfc_time[m] *= ts;
         }
-        if (p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
-        if (p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
+        // the planner's outputs belong to a run that included the planner: after a CORRIDOR-only run the device still holds the control
+        // points / coefficients of an earlier planner run (coef even rescaled by THAT run's time_scale), which do not go with the corridor
+        // just written -- they are not handed out, and the solver outcome reads "no QP solved"
+        const bool planned = (s->last_stages & RBP_STAGE_PLANNER) != 0;
+        if (planned && p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
+        if (planned && p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
         p.time_scale = ts;
-        p.total_cost = q[SC_TOTAL_COST];
-        p.qp_iterations = (int)q[SC_IPM_ITERS];
-        p.qp_solves = (int)q[SC_QP_SOLVED];
-        p.qp_unpolished = (int)(q[SC_QP_SOLVED] - q[SC_POLISHED]);
-        p.kkt_max = q[SC_KKT_MAX];
+        p.total_cost = planned ? q[SC_TOTAL_COST] : 0.0;
+        p.qp_iterations = planned ? (int)q[SC_IPM_ITERS] : 0;
+        p.qp_solves = planned ? (int)q[SC_QP_SOLVED] : 0;
+        p.qp_unpolished = planned ? (int)(q[SC_QP_SOLVED] - q[SC_POLISHED]) : 0;
+        p.kkt_max = planned ? q[SC_KKT_MAX] : 0.0;
         if (biter > 0) {
             int last = biter - 1, nb = std::min(bs, N - last * bs);
             p.x_size = 3 * nb * oqq;

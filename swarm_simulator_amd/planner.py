@@ -32,6 +32,9 @@ class RbpLibraryMissing(RuntimeError):
     pass
 
 
+preloaded_hip_runtime = []   # torch's HIP runtime libraries loaded ahead of librbp_hip.so by lib() (empty: none)
+
+
 def lib():
     """Load lib/librbp_hip.so; fails loudly if it was not built."""
     global _lib
@@ -43,16 +46,24 @@ def lib():
         # (if this library's /opt/rocm runtime is in the process first, torch.cuda reports "No HIP GPUs are available"); with torch's
         # copies loaded first, both sides share one runtime whatever the import order -- which streams, events and device pointers
         # exchanged between them (bench.py, sharded.py) rely on.
-        try:
+        # RBP_PRELOAD_TORCH_HIP=0 switches the preload off (a process that never imports torch); what was preloaded is recorded in
+        # `preloaded_hip_runtime` and a failure is reported, not swallowed.
+        global preloaded_hip_runtime
+        if os.environ.get("RBP_PRELOAD_TORCH_HIP", "1") != "0":
             import importlib.util
             sp = importlib.util.find_spec("torch")
             if sp is not None and sp.submodule_search_locations:
                 tl = os.path.join(list(sp.submodule_search_locations)[0], "lib")
                 for n in ("libhsa-runtime64.so", "libamdhip64.so"):
-                    if os.path.exists(os.path.join(tl, n)):
-                        C.CDLL(os.path.join(tl, n), mode=C.RTLD_GLOBAL)
-        except Exception:
-            pass
+                    f = os.path.join(tl, n)
+                    if os.path.exists(f):
+                        try:
+                            C.CDLL(f, mode=C.RTLD_GLOBAL)
+                            preloaded_hip_runtime.append(f)
+                        except OSError as e:
+                            import warnings
+                            warnings.warn(f"swarm_simulator_amd: could not preload torch's {n} ({e}); torch.cuda may not see the GPU "
+                                          f"if it is imported after this library")
         L = C.CDLL(path)
         P = C.POINTER
         L.rbp_version.restype = C.c_char_p

@@ -132,9 +132,16 @@ def test_corridor_only_run_after_a_planner_run_is_not_time_scaled():
     assert sess.download() == [0]
     assert g.time_scale > 1.0 and np.allclose(g.T, T0 * g.time_scale, rtol=0, atol=1e-12)
     scaled = g.sfc_time.copy()
+    coef_planned, solves = g.coef.copy(), g.qp_solves
+    assert solves > 0
+    g.coef[:] = -7.0   # (host buffers the corridor-only download must leave alone)
+    g.ctrl[:] = -7.0
     sess.run(A.RBP_STAGE_CORRIDOR)
     assert sess.download() == [0]
     assert g.time_scale == 1.0 and np.array_equal(g.T, T0)
+    # ... and the earlier planner run's outputs (coef rescaled by ITS time_scale) are not handed out as if they went with this corridor
+    assert np.all(g.coef == -7.0) and np.all(g.ctrl == -7.0) and g.qp_solves == 0 and g.total_cost == 0.0
+    assert not np.array_equal(coef_planned, g.coef)
     assert np.allclose(g.sfc_time * 1.0, scaled / scaled.max() * g.sfc_time.max(), rtol=1e-12, atol=0)  # same boxes, unscaled
     assert g.sfc_time.max() == T0[-1]
     sess.close()
