@@ -489,8 +489,11 @@ def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "256-agent mission derived from the reference's 64-agent pattern (tools/make_mission_256.py; no such file upstream), worlds/map1.bt",
             "config": {"workload": f"ONE {m.qn}-agent mission (M={pr.M}), Corridor::update sharded by agent over {n_ranks} rank(s) + one fused "
-                                   f"all-gather, RBPPlanner sweep sequential batch_size={args.batch_size}; host buffers in and out",
-                       "agents": m.qn, "segments": pr.M, "parallelism": f"agents sharded over {n_ranks} GPU(s) (corridor), planner sweep per rank",
+                                   f"all-gather, " + ("RBPPlanner JOINT QP (plan/sequential=false: knot blocks of order 9 N, grid-wide solver "
+                                                      "kernels/jqp.hip), replicated on every rank" if args.joint else
+                                                      f"RBPPlanner sweep sequential batch_size={args.batch_size}") + "; host buffers in and out",
+                       "agents": m.qn, "segments": pr.M, "parallelism": f"agents sharded over {n_ranks} GPU(s) (corridor), planner per rank",
+                       "qp_iterations": pr.qp_iterations,
                        "baseline_config": "c4", "qp_unpolished": pr.qp_unpolished, "kkt_max": pr.kkt_max, "all_missions_ok": bool(ok)}}))
     if dist is not None:
         dist.destroy_process_group()
