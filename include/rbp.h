@@ -144,7 +144,12 @@ int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_p
 /* ---- device-resident, batched form (what bench.py times) --------------------------------------
  * A session owns the HBM copies of K independent missions (e.g. the 50-map sweep of
  * swarm_traj_planner_rbp_test_all.cpp:49-103).  `run` only enqueues kernels on `stream`
- * (a hipStream_t passed as void*; NULL = default stream) and never synchronises. */
+ * (a hipStream_t passed as void*; NULL = default stream) and never synchronises -- with ONE exception: the PLANNER stage of a
+ * non-sequential plan (plan/sequential = false, the reference's code default param.hpp:67: one joint QP over all agents,
+ * rbp_planner.hpp:857-859) with more than 32 agents runs on the grid-wide solver (kernels/jqp.hip: a launch per phase of the
+ * interior-point method over all CUs), whose host loop learns once per iteration whether any mission is still running: that
+ * `run` SYNCHRONISES `stream` before it returns.  RBP_JOINT_WIDE=0 / 1 forces the one-workgroup kernel (<= 64 agents, no
+ * synchronisation) / the grid-wide solver. */
 typedef struct rbp_session rbp_session;
 
 enum { RBP_STAGE_CORRIDOR = 1, RBP_STAGE_PLANNER = 2, RBP_STAGE_ALL = 3 };
