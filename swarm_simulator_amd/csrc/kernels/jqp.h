@@ -22,6 +22,7 @@ struct JArgs {
     int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;
+    double pol_lh_early, pol_lh_final;  // block Lawson-Hanson rounds allowed in an early / the final polish attempt
     double tune[5];  // mu0, slack floor, centring exponent, neighbourhood gamma, step fraction
 };
 

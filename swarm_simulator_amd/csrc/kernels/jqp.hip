@@ -1354,6 +1354,9 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0;
         if (e) sscanf(e, "%d,%lf,%lf", &A.dreg_mode, &A.dreg_scale, &A.dreg_max);
         A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
+        A.pol_lh_early = 60, A.pol_lh_final = 160;
+        const char* pl = getenv("RBP_JQ_LH");  // experiments: "early,final" round caps of the polish's Lawson-Hanson fallback
+        if (pl) sscanf(pl, "%lf,%lf", &A.pol_lh_early, &A.pol_lh_final);
         const char* t = getenv("RBP_JQ_TUNE");  // experiments: "mu0,sfloor,sigma exponent,neighbourhood gamma,step fraction"
         if (t) sscanf(t, "%lf,%lf,%lf,%lf,%lf", &A.tune[0], &A.tune[1], &A.tune[2], &A.tune[3], &A.tune[4]);
     }
@@ -1429,7 +1432,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jp_c0, dim3(npost, K), 0, A);
         JQ_LAUNCH(jp_chain_mv, dim3((dm.nj * 9 * N + 255) / 256, K), 0, A, 0);
         JQ_LAUNCH(jq_sweep<PASS_CAND>, dim3(nsw, K), 0, A);
-        for (int guard = 0; guard < 400; ++guard) {
+        for (int guard = 0; guard < 4000; ++guard) {
             if (!poll()) return RBP_ERR_HIP;
             bool any_new = false, any_bpp = false, any_primal = false, any_refine = false;
             int nc_max = 0, nblk_max = 0;
