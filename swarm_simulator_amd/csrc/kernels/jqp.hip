@@ -977,19 +977,21 @@ __device__ __forceinline__ void store_pivot_inverse(const double* Am, double* Pg
     }
 }
 
-// first pivot of a knot (the others are inverted by the update kernel's look-ahead)
-__global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int mid) {
+// pivot tile of step k.  k = 0: first pivot of a knot; k > 0: only in the bulk schedule (many workgroups per launch), where the update
+// kernel has no look-ahead (jq_update_bulk)
+__global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
-    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, 0, chain);
-    if (!c.active) return;
+    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
+    if (!c.active || k >= c.nblk) return;
     __shared__ double Am[JT * LDA];
     __shared__ InvScratch sc;
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
-    for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = c.src[i];  // tile (0, 0)
+    const double* tkk = c.src + ((size_t)k * c.nblk + k) * JTT;  // pivot tile (k, k) as the steps before k left it
+    for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = tkk[i];
     __syncthreads();
     inv64_lds(Am, &sc, &bad);
     store_pivot_inverse(Am, c.Pk);
@@ -1144,6 +1146,89 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         store_pivot_inverse(Am, c.Pn);
         if (bad && tid == 0) *c.bad += 1.0;
     }
+}
+
+
+// The same update for launches with thousands of tiles (many resident missions, or one 256-agent mission): no look-ahead -- the next pivot
+// is inverted by jq_pivot0(k + 1) in a launch of its own --, hence no LDS (the look-ahead scratch costs every workgroup of jq_update 61 KB),
+// operands of ONE 16-column chunk at a time and a register budget for three workgroups per CU.
+__global__ __launch_bounds__(256, 3) void jq_update_bulk(JArgs A, int kind, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y;
+    const Ws w = carve(A, mission);
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
+    const int nblk = c.nblk;
+    if (!c.active || (int)blockIdx.x >= nblk * (nblk + 1) / 2) return;
+    int I = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    if (I * (I + 1) / 2 > (int)blockIdx.x) I--;
+    if ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
+    const int J = blockIdx.x - I * (I + 1) / 2;
+    const bool last = k == nblk - 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    double* out = c.dst + ((size_t)I * nblk + J) * JTT;
+    double* outT = c.dst + ((size_t)J * nblk + I) * JTT;
+    const double sgn = last ? -1.0 : 1.0;
+    if (I == k || J == k) {
+        const double* src = (I == k && J == k) ? c.Pk : (J == k ? c.Y + (size_t)I * JTT : c.Y + (size_t)J * JTT);
+        const bool tr = (I == k && J != k);
+        const double f = (I == k && J == k) ? -sgn : sgn;
+        for (int i = tid; i < JTT; i += 256) {
+            const int r = i >> 6, cc = i & 63;
+            const double v = f * (tr ? src[(size_t)cc * JT + r] : src[i]);
+            out[i] = v;
+            if (last && I != J) outT[(size_t)cc * JT + r] = v;
+        }
+        return;
+    }
+    const bool trJ = J < k;
+    const double* Zt = c.src + (trJ ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
+    const double* Yt = c.Y + (size_t)I * JTT;
+    const double* Ct = c.src + ((size_t)I * nblk + J) * JTT;
+    double cv[2][2][4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[ti][tj][r] = Ct[(size_t)(32 * wr + 16 * ti + lg + 4 * r) * JT + 32 * wc + 16 * tj + li];
+    d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        d4 yf[2], zf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            yf[t] = *reinterpret_cast<const d4*>(Yt + (size_t)(32 * wr + 16 * t + li) * JT + 16 * ch + 4 * lg);
+            if (!trJ) {
+                zf[t] = *reinterpret_cast<const d4*>(Zt + (size_t)(32 * wc + 16 * t + li) * JT + 16 * ch + 4 * lg);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zf[t][q] = Zt[(size_t)(16 * ch + 4 * lg + q) * JT + 32 * wc + 16 * t + li];
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[ti][q], zf[tj][q], acc[ti][tj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = sgn * (cv[ti][tj][r] - acc[ti][tj][r]);
+                const int rr = 32 * wr + 16 * ti + lg + 4 * r, cc = 32 * wc + 16 * tj + li;
+                out[(size_t)rr * JT + cc] = v;
+                if (last && I != J) outT[(size_t)cc * JT + rr] = v;
+            }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1400,13 +1485,22 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         }
         A.ref_step = 0;
     };
+    // two schedules of the sweep: look-ahead (the workgroup that updates the next pivot tile inverts it: one dependent launch less per
+    // step -- a lone mission is bound by that chain) / bulk (thousands of tiles per launch: a leaner update kernel at three workgroups per
+    // CU, the pivot inverse in a launch of its own)
+    const char* be = getenv("RBP_JQ_SCHED");  // "look" | "bulk" (A/B runs: tools/joint_sched_ab.sh)
+    const bool bulk = be ? be[0] == 'b' : K >= 8 && (size_t)K * 2 * ntri >= 1024;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
-        JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid);
+        JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, 0);
         for (int k = 0; k < nblk; ++k) {
+            if (bulk && k > 0) JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, k);
             if (nblk > 1) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, 0, sidx, mid, k);
-            JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
+            if (bulk)
+                JQ_LAUNCH(jq_update_bulk, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
+            else
+                JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
         }
     };
     const bool trace = getenv("RBP_JOINT_TRACE") != nullptr;
@@ -1461,7 +1555,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             } else if (any_bpp) {
                 if (nblk_max > 0) {
                     JQ_LAUNCH(jp_gather, dim3(nblk_max * nblk_max, K), 0, A);
-                    JQ_LAUNCH(jq_pivot0, dim3(1, 1, K), 0, A, 1, 0, 0);
+                    JQ_LAUNCH(jq_pivot0, dim3(1, 1, K), 0, A, 1, 0, 0, 0);
                     for (int k = 0; k < nblk_max; ++k) {
                         if (nblk_max > 1) JQ_LAUNCH(jq_panel, dim3(nblk_max, 1, K), 0, A, 1, 0, 0, k);
                         JQ_LAUNCH(jq_update, dim3(nblk_max * (nblk_max + 1) / 2, 1, K), 0, A, 1, 0, 0, k);
@@ -1541,6 +1635,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jq_count, dim3(K), 0, A);
         for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
         factor_knot(0, 1);
+        if (hipPeekAtLastError() != hipSuccess) return RBP_ERR_HIP;  // (a launch the device refuses must not pass for a QP that does not converge)
         solve(0);
         JQ_LAUNCH(jq_sweep<PASS_AFF>, dim3(nsw, K), 0, A);
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 2, 0);
