@@ -20,7 +20,7 @@
 #include "rbp_dev.h"
 
 // SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
-#define SFC_WAVES 4         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
+#define SFC_WAVES 8         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
 typedef short sfc_key_t;             // a voxel index along one axis (< 4096), -1 outside the grid
 typedef unsigned short sfc_log_t;    // box_log entries: a run length of waypoints (<= M + 1)
 
@@ -47,7 +47,7 @@ struct AxisCache {
 // Either way the keys are exactly the reference's.  c0 > 0 continues a list whose upper end grew (same lo).
 // zmask / zneg (used for the z axis): OR of 1 << key over the valid samples, index of the first sample outside the grid.
 __device__ __noinline__ int axis_keys_chain(sfc_key_t* keys, int cap, double lo, double hi, double step, double world_lo, double rf, int key_min,
-                                            int dim, unsigned* zmask, int* zneg) {
+                                            int dim, AxisCache* out) {
     int c = 0;
     unsigned zm = 0;
     int zn = -1;
@@ -61,16 +61,17 @@ __device__ __noinline__ int axis_keys_chain(sfc_key_t* keys, int cap, double lo,
         if (in && k < 32) zm |= 1u << k;
         if (!in && zn < 0) zn = c;
     }
-    *zmask = zm, *zneg = zn;
+    out->zmask = zm, out->zneg = zn;  // (LDS: every lane writes the same values)
     return c;
 }
 
+// `out` (LDS) receives zmask / zneg; c0 > 0: they continue from out's values
 __device__ __forceinline__ int axis_keys(const bool WANT_Z, sfc_key_t* keys, int cap, double lo, double hi, double step, double world_lo,
-                                         double rf, int key_min, int dim, int c0, unsigned* zmask, int* zneg, int lane) {
+                                         double rf, int key_min, int dim, int c0, AxisCache* out, int lane) {
     const double lim = hi + SP_EPSILON_FLOAT;
     const double vmax = fmax(fabs(lo), fabs(lim) + step);
     const bool nudge_down = lo > world_lo + SP_EPSILON_FLOAT;
-    int c = c0, zn = *zneg;
+    int c = c0, zn = c0 > 0 ? out->zneg : -1;
     unsigned zm = 0;
     bool unproven = false;
 #ifndef SFC_FORCE_CHAIN  // (test builds: always take the chain, to check that both routes give the reference's keys)
@@ -110,11 +111,11 @@ __device__ __forceinline__ int axis_keys(const bool WANT_Z, sfc_key_t* keys, int
 #else
     unproven = true;
 #endif
-    if (unproven) return axis_keys_chain(keys, cap, lo, hi, step, world_lo, rf, key_min, dim, zmask, zneg);
+    if (unproven) return axis_keys_chain(keys, cap, lo, hi, step, world_lo, rf, key_min, dim, out);
     if (WANT_Z) {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) zm |= __shfl_xor(zm, o);
-        *zmask |= zm, *zneg = zn;
+        out->zmask = (c0 > 0 ? out->zmask : 0u) | zm, out->zneg = zn;
     }
     return c;
 }
@@ -130,7 +131,8 @@ struct SfcCtx {
     sfc_key_t* keys[3];   // LDS, full extent of the box along each axis
     sfc_key_t* skeys[3];  // LDS, the short axis of the slab under test
     int cap[3];           // capacity of keys[a]
-    AxisCache cache[3], slab[3];
+    AxisCache* cache;     // LDS (wave-private): extents and sizes of the key lists keys[] / skeys[] hold
+    AxisCache* slab;
     unsigned long long samples;
 #ifdef SFC_PROFILE
     long long t_keys, t_samp;
@@ -159,21 +161,15 @@ __device__ bool is_obstacle_in_box(SfcCtx& c, const double* box, int lane) {
         } else if (sl.lo == lo && sl.hi == hi) {
             slab = true;
         } else if (f.lo == lo && hi > f.hi && f.n > 0) {  // upper end grew: the samples so far stay, append the new ones
-            unsigned zm = f.zmask;
-            int zn = f.zneg;
-            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, &zm, &zn, lane);
-            f.hi = hi, f.zmask = zm, f.zneg = zn;
+            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], f.n, &f, lane);
+            f.hi = hi;
         } else if (hi - lo < (SFC_SLAB - 3) * c.res[a]) {
-            unsigned zm = 0;
-            int zn = -1;
-            sl.n = axis_keys(a == 2, c.skeys[a], SFC_SLAB, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
-            sl.lo = lo, sl.hi = hi, sl.zmask = zm, sl.zneg = zn;
+            sl.n = axis_keys(a == 2, c.skeys[a], SFC_SLAB, lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &sl, lane);
+            sl.lo = lo, sl.hi = hi;
             slab = true;
         } else {
-            unsigned zm = 0;
-            int zn = -1;
-            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &zm, &zn, lane);
-            f.lo = lo, f.hi = hi, f.zmask = zm, f.zneg = zn;
+            f.n = axis_keys(a == 2, c.keys[a], c.cap[a], lo, hi, c.res[a], c.world_min[a], c.rf, c.key_min[a], c.dim[a], 0, &f, lane);
+            f.lo = lo, f.hi = hi;
         }
         kp[a] = slab ? c.skeys[a] : c.keys[a], n[a] = slab ? sl.n : f.n;
         if (a == 2) zmask = slab ? sl.zmask : f.zmask, zneg = slab ? sl.zneg : f.zneg;
@@ -375,7 +371,7 @@ __global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
 }
 
 #ifndef SFC_WAVES_PER_EU
-#define SFC_WAVES_PER_EU 3
+#define SFC_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(DevSession s) {
 #ifdef SFC_PROFILE
@@ -406,7 +402,11 @@ __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(D
     }
     __syncthreads();
     if (qi >= s.agent_end) return;
+    // what the key lists hold (extent, count, z summary) lives in LDS beside them: wave-uniform state that is read once per box test
+    // has no business occupying 42 vector registers for the whole kernel
+    __shared__ AxisCache caches[SFC_WAVES][6];
     SfcCtx c;
+    c.cache = caches[wave], c.slab = caches[wave] + 3;
     c.grid = w.dist;
     c.rf = 1.0 / w.res;
 #pragma unroll
