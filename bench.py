@@ -216,6 +216,31 @@ def single_sweep_rate(mission_file_agents, param, steps=3):
             "note": "50 missions resident (map1..50, one workgroup each): one pass of the reference's own sweep"}
 
 
+def sweep_phase_rate(K, agents, resident_wgs=512):
+    """roofline.sweep_phase_gbs: the streaming part of qp_batch_kernel judged on its own.  A subprocess runs the SAME workload through the
+    developer build of the library that carries the in-kernel phase timers (lib/librbp_hip_prof.so, `make prof`; 100 MHz wall clock per
+    workgroup, tools/qp_phase_profile.py) and reports, summed over the missions, the bytes the row sweeps stream (rbp_dev.h
+    SC_SWEEP_BYTES: the sweep part of the algorithmic bytes) and the time the workgroups spend inside their sweep phases.  With
+    `resident_wgs` workgroups on the chip at a time (two per CU), chip-level rate = resident * bytes / time."""
+    import subprocess
+    lib = os.path.join(ROOT, "swarm_simulator_amd", "lib", "librbp_hip_prof.so")
+    if not os.path.exists(lib):
+        return None
+    env = dict(os.environ, RBP_HIP_LIB=lib, K=str(K), AGENTS=str(agents), BS="4", ITER="1", JSON="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "qp_phase_profile.py")], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode or not line:
+        return None
+    d = json.loads(line[-1])
+    if d["failed"] or d["sweep_ticks_100mhz"] <= 0:
+        return None
+    res = min(resident_wgs, d["missions"])
+    d["resident_workgroups"] = res
+    d["gbs"] = res * d["sweep_bytes"] / (d["sweep_ticks_100mhz"] / 1e8) / 1e9
+    d["sweep_share_of_kernel_time"] = d["sweep_ticks_100mhz"] / d["kernel_ticks_100mhz"]
+    return d
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` outside a torchrun environment: run the same command line with N ranks, one per GPU."""
     import socket
@@ -431,6 +456,17 @@ def main():
                 out["single_sweep"] = {"error": str(e)}
             # top-level scalars (summaries keep top-level keys only)
             lat, ss = out["latency_ms_single_mission"], out["single_sweep"]
+            try:  # the sweeps' own rate against the streaming roof (6.3 TB/s measured copy rate, 8 TB/s nominal)
+                sp = sweep_phase_rate(K, N)
+            except Exception:
+                sp = None
+            out["roofline"]["sweep_phase_gbs"] = sp["gbs"] if sp else None
+            out["roofline"]["sweep_phase"] = sp and {
+                "gbs": sp["gbs"], "frac_of_hbm_peak": sp["gbs"] / HBM_PEAK_GBS, "sweep_bytes_per_launch": sp["sweep_bytes"],
+                "sweep_share_of_kernel_time": sp["sweep_share_of_kernel_time"], "resident_workgroups": sp["resident_workgroups"],
+                "note": "algorithmic bytes of the row sweeps (BUILD, AFF, STEP, NBHD, UPDATE) / the time the workgroups spend in those "
+                        "phases (in-kernel 100 MHz timers of the profiling build, same workload, separate process), times the workgroups "
+                        "resident at a time; the timers add a barrier per phase, so this is a slight under-estimate"}
             out["single_mission_two_calls_ms"] = lat.get("two_calls_ms") if isinstance(lat, dict) else None
             out["single_sweep_value"] = ss.get("value") if isinstance(ss, dict) else None
         if world_size == 1 and not args.no_cpu_baseline:

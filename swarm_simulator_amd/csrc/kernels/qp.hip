@@ -2407,7 +2407,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     bool ok = false;
     int it_count = 0, polished = 0, early_tries = 0, fail_reason = 3;
     double gap_next = 0, pres_next = 0, kkt_ipm = 0;
-    double flops = 0, rows_swept = 0, row_bytes = 0;
+    double flops = 0, rows_swept = 0, row_bytes = 0, sweep_bytes = 0;
     // ALGORITHMIC HBM bytes of one interior-point iteration (the numerator of the HBM roofline): per row the three
     // sweeps read (s, z) three times and write them once (64 B), frozen rows also read their constant three times (+24 B); per free
     // control point the accumulators are written twice and read four times (288 B); the knot blocks: on the tiled path 8 block
@@ -2415,8 +2415,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     // wave path (round 3) T_j is written and read as a triangle and the knot's factor is ONE triangle, M_j = L_j^-T, written once and
     // staged four times (forward and backward pass of the two substitutions), plus the reciprocal pivots: 7 triangles + 5 nk
     const double blk_doubles = d.nk <= 36 ? 7.0 * (d.nk * (d.nk + 1) / 2) + 5.0 * d.nk : 8.0 * d.ldb * d.ldb;
-    const double bytes_iter = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6) +
-                              8.0 * (double)d.nj * blk_doubles;
+    const double bytes_sweeps = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6);
+    const double bytes_iter = bytes_sweeps + 8.0 * (double)d.nj * blk_doubles;
     PolishWs pw;
     pw.cand = (Cand*)w.polish;
     pw.V = w.polish + PL_NC * 14;
@@ -2609,7 +2609,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             __syncthreads();
         }
         rows_swept += 2 * nrows_free;
-        row_bytes += bytes_iter;
+        row_bytes += bytes_iter, sweep_bytes += bytes_sweeps;
         PROF(10);
         PROF(11);
     }
@@ -2661,6 +2661,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         scal[SC_ROWS] += rows_swept;
 #ifndef QP_LHSTATS
         scal[SC_ROW_BYTES] += row_bytes;
+        scal[SC_SWEEP_BYTES] += sweep_bytes;
 #endif
     }
     PROF_FLUSH(scal);

@@ -79,7 +79,8 @@ enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3,
        SC_KKT_MAX = 7,    // max over the batch QPs of the KKT residual of the accepted answer (see rbp_plan::kkt_max)
        SC_PROF0 = 8,      // SC_PROF0..SC_PROF0+15: per-phase cycle counters (QP_PROFILE builds); slot 8 otherwise: which batch was not polished
        SC_ROW_BYTES = 24, // algorithmic HBM bytes of the QP kernel (row state, row constants, knot blocks)
-       SC_N = 28 };
+       SC_SWEEP_BYTES = 28, // ... the part of SC_ROW_BYTES the three row sweeps of an interior-point iteration stream (bench.py: sweep_phase_gbs)
+       SC_N = 32 };
 enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
 int rbp_set_error(int code, const char* msg);  // abi/session.hip: records the message rbp_last_error() returns, returns code

@@ -11,7 +11,13 @@ NA = int(os.environ.get("AGENTS", "64"))
 m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), NA, p)
 s = planner.Session(worlds, [m] * K, p, plans)
 s.run(); st = s.download()
-sc = s.scalars(28)
+sc = s.scalars(32)
+if os.environ.get("JSON"):  # bench.py's sweep_phase_gbs leg: one line, nothing else
+    import json
+    sweeps = [1, 7, 9, 10, 11]  # BUILD, AFF, STEP, NBHD, UPDATE
+    print(json.dumps({"missions": K, "failed": int(np.count_nonzero(st)), "sweep_bytes": float(sc[:, 28].sum()),
+                      "sweep_ticks_100mhz": float(sc[:, [8 + i for i in sweeps]].sum()), "kernel_ticks_100mhz": float(sc[:, 8:20].sum())}))
+    sys.exit(0)
 names = ["polish (+tail)", "BUILD sweep", "grad+FT+norms", "assemble", "factor", "rhs glue", "solve", "AFF sweep", "batch setup", "STEP sweep", "NBHD sweeps", "UPDATE sweep"]
 tot = sc[:, 8:20].sum(1)
 print("missions", len(st), "failed", int(np.count_nonzero(st)), "IPM iterations per mission", sc[:, 2].mean())
