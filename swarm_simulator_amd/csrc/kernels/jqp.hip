@@ -915,6 +915,63 @@ __device__ __forceinline__ bool gj16_lds(double* D, int lane) {
     }
     return ok;
 }
+// The same Gauss-Jordan inverse with the matrix in REGISTERS for all sixteen column steps (lane (r, g) owns D[r][4g .. 4g+3]): the pivot is a
+// v_readlane (scalar), the pivot row's segment comes from lane (c, g) of the lane's own row of sixteen by DPP row_newbcast, the row's entry
+// in the pivot column from the row of sixteen g0 = c / 4 by the gfx950 lane swaps (v_permlane32_swap + v_permlane16_swap: two VALU
+// operations per dword instead of an LDS round trip with its write, fence and read).  In / out through LDS as gj16_lds.
+template <int DPP_CTRL>
+__device__ __forceinline__ double dpp_bcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), DPP_CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), DPP_CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int G0>
+__device__ __forceinline__ unsigned rows_bcast32(unsigned x) {  // every row of sixteen lanes receives row G0, position by position
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 a = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // a[0] = rows (0, 1, 0, 1), a[1] = rows (2, 3, 2, 3)
+    const unsigned y = G0 < 2 ? a[0] : a[1];
+    const u2 b = __builtin_amdgcn_permlane16_swap(y, y, false, false);  // b[0] = the even row of y four times, b[1] = the odd one
+    return (G0 & 1) ? b[1] : b[0];
+}
+template <int G0>
+__device__ __forceinline__ double rows_bcast(double v) {
+    return __hiloint2double((int)rows_bcast32<G0>((unsigned)__double2hiint(v)), (int)rows_bcast32<G0>((unsigned)__double2loint(v)));
+}
+template <int C>
+__device__ __forceinline__ void gj16_step(double (&v)[4], int r, int g, bool& ok) {
+    constexpr int G0 = C / 4, Q0 = C % 4;
+    const double p = rl(v[Q0], C + 16 * G0);
+    const double f = rows_bcast<G0>(v[Q0]);
+    double pr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pr[q] = dpp_bcast<0x150 + C>(v[q]);
+    ok = ok && (p > 0.0);
+    const double ip = fast_rcp(p), fi = f * ip;
+    if (r == C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = pr[q] * ip;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] -= fi * pr[q];
+    }
+    if (g == G0) v[Q0] = r == C ? ip : -fi;
+}
+__device__ __forceinline__ bool gj16_reg(double* D, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = D[r * 18 + 4 * g + q];
+    bool ok = true;
+    gj16_step<0>(v, r, g, ok), gj16_step<1>(v, r, g, ok), gj16_step<2>(v, r, g, ok), gj16_step<3>(v, r, g, ok);
+    gj16_step<4>(v, r, g, ok), gj16_step<5>(v, r, g, ok), gj16_step<6>(v, r, g, ok), gj16_step<7>(v, r, g, ok);
+    gj16_step<8>(v, r, g, ok), gj16_step<9>(v, r, g, ok), gj16_step<10>(v, r, g, ok), gj16_step<11>(v, r, g, ok);
+    gj16_step<12>(v, r, g, ok), gj16_step<13>(v, r, g, ok), gj16_step<14>(v, r, g, ok), gj16_step<15>(v, r, g, ok);
+    JQ_WSYNC();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = v[q];
+    JQ_WSYNC();
+    return ok;
+}
 __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     for (int kk = 0; kk < 4; ++kk) {
