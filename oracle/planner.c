@@ -854,6 +854,58 @@ static int qp_solve(const qp_t* q, const double* x0, const oracle_qp_options* op
                 }
             }
         }
+        /* EXPERIMENT (env ORACLE_GONDZIO = number of correctors, default 0 = off; not part of the checked path): Gondzio's multiple
+         * centrality correctors on top of Mehrotra's direction.  Each corrector re-solves with the complementarity target moved by the
+         * accumulated term T (products of the trial point projected onto [bmin, bmax] * sigma mu) and is kept if the step grows. */
+        {
+            static int ngond = -1;
+            if (ngond < 0) ngond = getenv("ORACLE_GONDZIO") ? atoi(getenv("ORACLE_GONDZIO")) : 0;
+            if (ngond > 0) {
+                double* T = (double*)calloc(nc, sizeof(double));
+                double* tn = (double*)malloc(sizeof(double) * nc);
+                double* dx2 = (double*)malloc(sizeof(double) * nx);
+                double* dy2 = (double*)malloc(sizeof(double) * ne);
+                double* ds2 = (double*)malloc(sizeof(double) * nc);
+                double* dz2 = (double*)malloc(sizeof(double) * nc);
+                const double dalpha = getenv("OG_DA") ? atof(getenv("OG_DA")) : 0.3, bmin = getenv("OG_BMIN") ? atof(getenv("OG_BMIN")) : 0.1, bmax = getenv("OG_BMAX") ? atof(getenv("OG_BMAX")) : 10.0;
+                const double mut = fmax(sigma * mu, 1e-3 * mu);
+                for (int k = 0; k < ngond; ++k) {
+                    const double ap = fmin(1.0, 0.99 * alpha);
+                    if (ap >= 1.0) break;
+                    const double at = fmin(1.0, ap + dalpha);
+                    for (int c = 0; c < nc; ++c) {
+                        double v = (s[c] + at * ds[c]) * (z[c] + at * dz[c]);
+                        double vt = v < bmin * mut ? bmin * mut : (v > bmax * mut ? bmax * mut : v);
+                        double t = vt - v;
+                        if (t < -bmax * mut) t = -bmax * mut;
+                        tn[c] = T[c] + t;
+                    }
+                    for (int c = 0; c < nc; ++c) {
+                        double rcc = s[c] * z[c] + dsa[c] * dza[c] - sigma * mu - tn[c];
+                        tc[c] = -w[c] * (rg[c] - rcc / z[c]);
+                    }
+                    for (int i = 0; i < nx; ++i) r1[i] = -rd[i];
+                    op_GTz_add(q, tc, r1);
+                    kkt_solve(&K, r1, r2, dx2, dy2);
+                    op_Gx(q, dx2, ds2);
+                    double a2 = 1e300;
+                    for (int c = 0; c < nc; ++c) {
+                        double gdx = ds2[c], rcc = s[c] * z[c] + dsa[c] * dza[c] - sigma * mu - tn[c];
+                        dz2[c] = w[c] * (gdx + rg[c] - rcc / z[c]);
+                        ds2[c] = (-rcc - s[c] * dz2[c]) / z[c];
+                        if (ds2[c] < 0) a2 = fmin(a2, -s[c] / ds2[c]);
+                        if (dz2[c] < 0) a2 = fmin(a2, -z[c] / dz2[c]);
+                    }
+                    if (opt->verbose > 1) printf("      gondzio %d: alpha %.4f -> %.4f\n", k, ap, fmin(1.0, 0.99 * a2));
+                    if (fmin(1.0, 0.99 * a2) < ap + 0.1 * dalpha) break;
+                    memcpy(T, tn, sizeof(double) * nc);
+                    memcpy(dx, dx2, sizeof(double) * nx), memcpy(dy, dy2, sizeof(double) * ne);
+                    memcpy(ds, ds2, sizeof(double) * nc), memcpy(dz, dz2, sizeof(double) * nc);
+                    alpha = a2;
+                }
+                free(T), free(tn), free(dx2), free(dy2), free(ds2), free(dz2);
+            }
+        }
         alpha = fmin(1.0, 0.99 * alpha);
         /* stay in the wide neighbourhood N_-inf(gamma): no complementarity product may fall below gamma * mu(alpha).
          * Without this a few products collapse early and the iteration jams (alpha -> 0) near the solution. */

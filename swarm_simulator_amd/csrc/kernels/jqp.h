@@ -11,6 +11,7 @@ struct JLayout {
     size_t o_state, o_segsc, o_Lk, o_Dk, o_Ek, o_boxlo, o_boxhi, o_dxa, o_dx, o_rbase, o_rhs, o_wv, o_red;
     size_t o_bs[2], o_bz[2], o_ps[2], o_pz[2], o_pwgt, o_acc, o_Y, o_P, o_scr, o_inv;
     size_t o_pol;  // polish workspace (jqp_polish.inc)
+    size_t o_rhsc, o_dx2, o_tb, o_tp;  // centrality corrector: the corrector's right-hand side, the trial direction, the rows' target shifts
 };
 
 struct JArgs {
@@ -20,8 +21,10 @@ struct JArgs {
     int ref_step;   // which refinement step of a Newton solve the launch belongs to (kernels of step r skip missions with ST_NREF <= r)
     int retry_only; // launches that repeat a refused step: only missions with ST_RETRY set take part
     int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
+    int gond_only;  // launches of the centrality corrector: only missions with ST_GACT set take part
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;
+    double exit_mu;  // third exit of the interior-point loop: pres < 1e-9, dres < 1e-7, mu < exit_mu
     double pol_lh_early, pol_lh_final;  // block Lawson-Hanson rounds allowed in an early / the final polish attempt
     double tune[5];  // mu0, slack floor, centring exponent, neighbourhood gamma, step fraction
 };

@@ -49,7 +49,11 @@ constexpr double JQ_MU0 = 3e-1, JQ_SFLOOR = 1e-1, JQ_DREG = 1e-9, JQ_STEP_FRAC =
 enum { ST_STATE = 0 /* 0 running, 1 converged, 2 failed */, ST_ITER, ST_PAR /* which (s, z) pair is current */, ST_RETRY, ST_MU, ST_GAP, ST_PRES,
        ST_DRES, ST_SIGMU, ST_ALPHA, ST_APPLIED, ST_BT, ST_NROWS, ST_KKT, ST_FLOPS, ST_REASON, ST_AAFF, ST_POLISHED,
        ST_GO /* polish requested for this mission (set by the control kernel, cleared by the polish) */, ST_FINAL /* ... after convergence */,
-       ST_TRIES /* early polish attempts so far */, ST_NREF /* refinement steps per Newton solve in this iteration */, ST_BADPIV, ST_DREG /* dual regularisation of this iteration's Newton system */, ST_DREGN /* ... of the next */, ST_PSTATE /* polish: see jqp_polish.inc */, ST_RDONE, ST_N = 32 };
+       ST_TRIES /* early polish attempts so far */, ST_NREF /* refinement steps per Newton solve in this iteration */, ST_BADPIV, ST_DREG /* dual regularisation of this iteration's Newton system */, ST_DREGN /* ... of the next */, ST_PSTATE /* polish: see jqp_polish.inc */, ST_RDONE,
+       ST_GACT /* centrality corrector: this mission tries one */, ST_GOK /* ... and took it: dx and the rows' target shifts T are in force */,
+       ST_ATR /* trial step length */, ST_AP /* step length of the Mehrotra direction */,
+       ST_PACC /* the iterate before the last step was acceptable (pres < 1e-9, dres < 1e-7, mu < 5e-8) */, ST_PMU, ST_PPRES, ST_PDRES,
+       ST_REVERT /* the last step is being taken back (jq_unstep) */, ST_N = 40 };
 // reduction slots (each [4 components][nred workgroups])
 enum { RS_BUILD = 0 /* sum0 = gap, vmax = pres */, RS_POST /* dmax, gmax */, RS_AFF /* vmax, sum0, sum1, sum2 */, RS_STEP /* vmax */,
        RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_VERIFY /* polish: worst violation at the trial point */, RS_NSLOT };
@@ -95,7 +99,7 @@ __device__ inline double block_reduce(double v, int op, double* red /* >= 4 doub
 
 struct Ws {  // pointers into one mission's workspace
     double *st, *segsc, *Lk, *Dk, *Ek, *boxlo, *boxhi;
-    double *bs[2], *bz[2], *ps[2], *pz[2], *pwgt, *acc, *dxa, *dx, *rbase, *rhs, *wv, *red, *Y, *P, *scr, *inv;
+    double *bs[2], *bz[2], *ps[2], *pz[2], *pwgt, *acc, *dxa, *dx, *rbase, *rhs, *wv, *red, *Y, *P, *scr, *inv, *rhsc, *dx2, *tb, *tp;
 };
 __device__ __forceinline__ Ws carve(const JArgs& A, int mission) {
     double* b = A.ws + (size_t)mission * A.L.stride;
@@ -106,6 +110,7 @@ __device__ __forceinline__ Ws carve(const JArgs& A, int mission) {
     for (int p = 0; p < 2; ++p) w.bs[p] = b + L.o_bs[p], w.bz[p] = b + L.o_bz[p], w.ps[p] = b + L.o_ps[p], w.pz[p] = b + L.o_pz[p];
     w.pwgt = b + L.o_pwgt, w.acc = b + L.o_acc, w.dxa = b + L.o_dxa, w.dx = b + L.o_dx, w.rbase = b + L.o_rbase, w.rhs = b + L.o_rhs;
     w.wv = b + L.o_wv, w.red = b + L.o_red, w.Y = b + L.o_Y, w.P = b + L.o_P, w.scr = b + L.o_scr, w.inv = b + L.o_inv;
+    w.rhsc = b + L.o_rhsc, w.dx2 = b + L.o_dx2, w.tb = b + L.o_tb, w.tp = b + L.o_tp;
     return w;
 }
 __device__ __forceinline__ double* red_slot(const Ws& w, const JLayout& L, int slot, int comp) { return w.red + ((size_t)slot * 4 + comp) * L.nred; }
@@ -212,17 +217,19 @@ __global__ __launch_bounds__(256) void jq_setup(JArgs A) {
 // Control points j6 < 3 and j6 >= 6M - 3 are pinned: their rows are constants, checked once (PASS_INIT) against 1e-6.
 // ------------------------------------------------------------------------------------------------------------------------
 enum { PASS_INIT = 0, PASS_BUILD, PASS_AFF, PASS_STEP, PASS_UPBUILD, PASS_CAND, PASS_VERIFY,
-       PASS_KMUL_A /* J'W J dxa for the iterative refinement of a Newton solve */, PASS_KMUL_D /* ... of dx */ };
+       PASS_KMUL_A /* J'W J dxa for the iterative refinement of a Newton solve */, PASS_KMUL_D /* ... of dx */, PASS_KMUL_G /* ... of dx2 */,
+       PASS_GOND /* centrality corrector: target shifts T of the rows and the change of the right-hand side */,
+       PASS_STEPG /* step length of the trial direction dx2 with T */ };
 
 struct PassIO {
-    double sigma_mu, alpha, dreg, dregn, mu0, sfloor;
+    double sigma_mu, alpha, dreg, dregn, mu0, sfloor, atr, mut;
     double sum0, sum1, sum2, vmax, vmin;
 };
 
 // one row: see row_op in qp.hip (same arithmetic).  s, z: current state; out: new state (INIT, UPBUILD) through so / zo2.
 template <int PASS>
 __device__ __forceinline__ void row_op(double slack, double ga, double gd, double s, double z, PassIO& io, double cw, double& wgt, double& v,
-                                       double& zo, double& sn_out, double& zn_out) {
+                                       double& zo, double& sn_out, double& zn_out, double tt = 0.0) {
     if (PASS == PASS_INIT) {
         const double s0 = slack < io.sfloor ? io.sfloor : slack;
         sn_out = s0, zn_out = io.mu0 / s0;
@@ -244,23 +251,41 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
         io.sum0 += cw * s * z, io.sum1 += cw * (s * dza + z * dsa), io.sum2 += cw * cc;
         v = -wgt * (rg - s - cc * iz);
         wgt = wgt * iz;
-    } else if (PASS == PASS_STEP) {
+    } else if (PASS == PASS_STEP || PASS == PASS_STEPG) {
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
         const double dza = wgt * (ga + rg - s);
         const double cc = (-s - s * dza * iz) * dza;
-        const double rcc = s * z + cc - io.sigma_mu;
+        const double rcc = s * z + cc - io.sigma_mu - tt;
         const double dz = wgt * (gd + rg - rcc * iz);
         const double ds = -(rcc + s * dz) * iz;
         io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
+    } else if (PASS == PASS_GOND) {
+        // Gondzio's centrality corrector: at the trial step length the complementarity products of the Mehrotra direction are projected
+        // onto [0.1, 10] x (sigma mu); the shift t = projected - actual (not below -10 sigma mu) moves the row's target, and the
+        // direction is solved for again: rcc - t instead of rcc, i.e. the right-hand side changes by -G'(W t / z)
+        const double rg = s - slack;
+        const double iz = fast_rcp(z);
+        const double w0 = z * fast_rcp(s + io.dreg * z);
+        const double dza = w0 * (ga + rg - s);
+        const double cc = (-s - s * dza * iz) * dza;
+        const double rcc = s * z + cc - io.sigma_mu;
+        const double dz = w0 * (gd + rg - rcc * iz);
+        const double ds = -(rcc + s * dz) * iz;
+        const double pr = (s + io.atr * ds) * (z + io.atr * dz);
+        const double lo = 0.1 * io.mut, hi = 10.0 * io.mut;
+        double t = (pr < lo ? lo : (pr > hi ? hi : pr)) - pr;
+        t = fmax(t, -hi);
+        sn_out = t;
+        v = -w0 * t * iz;
     } else if (PASS == PASS_UPBUILD) {
         const double rg = s - (slack + io.alpha * gd);  // the old point: slack_old = slack + alpha * gd
         const double iz = fast_rcp(z);
         const double w0 = z * fast_rcp(s + io.dreg * z);
         const double dza = w0 * (ga + rg - s);
         const double cc = (-s - s * dza * iz) * dza;
-        const double rcc = s * z + cc - io.sigma_mu;
+        const double rcc = s * z + cc - io.sigma_mu - tt;
         const double dz = w0 * (gd + rg - rcc * iz);
         const double ds = -(rcc + s * dz) * iz;
         const double sn = s + io.alpha * ds, zn = z + io.alpha * dz;
@@ -272,7 +297,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, doubl
         zo = zn;
         io.sum0 += cw * sn * zn;
         io.vmax = fmax(io.vmax, fabs(rgn));
-    } else if (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D) {
+    } else if (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D || PASS == PASS_KMUL_G) {
         wgt = z * fast_rcp(s + io.dreg * z);  // the weight this iteration's Newton matrix was assembled with
         v = wgt * gd;
     }
@@ -290,8 +315,13 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     } else if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0)
         return;
     if (PASS == PASS_UPBUILD && A.retry_only && w.st[ST_RETRY] == 0.0) return;  // (a repeat launch: only for missions whose step was refused)
-    constexpr bool kmul = (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D);
-    if (kmul && w.st[ST_NREF] <= (double)A.ref_step) return;
+    constexpr bool kmulr = (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D || PASS == PASS_KMUL_G);
+    constexpr bool gond = (PASS == PASS_GOND);
+    constexpr bool kmul = kmulr || gond;  // (three accumulators per control point: G' v)
+    constexpr bool use_dx2 = (PASS == PASS_KMUL_G || PASS == PASS_STEPG);
+    if (kmulr && w.st[ST_NREF] <= (double)A.ref_step) return;
+    if ((gond || use_dx2 || A.gond_only) && w.st[ST_GACT] == 0.0) return;
+    const bool use_t = PASS == PASS_STEPG || (PASS == PASS_UPBUILD && w.st[ST_GOK] != 0.0);
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
     const int oq = d.oq, ncp = d.ncp;
@@ -307,14 +337,16 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     constexpr bool build = (PASS == PASS_BUILD || PASS == PASS_UPBUILD);
     constexpr bool aff = (PASS == PASS_AFF);
     constexpr bool accum = build || aff || kmul;
-    constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
-    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_VERIFY || kmul);
+    constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_STEPG || gond || PASS == PASS_UPBUILD);
+    constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_STEPG || PASS == PASS_UPBUILD || PASS == PASS_VERIFY || kmul);
     constexpr bool rd_sz = PASS != PASS_INIT && PASS != PASS_VERIFY;
     constexpr bool polish = (PASS == PASS_CAND || PASS == PASS_VERIFY);
     constexpr bool wr_sz = (PASS == PASS_INIT || PASS == PASS_UPBUILD);
     PassIO io;
     io.sigma_mu = w.st[ST_SIGMU], io.alpha = w.st[ST_ALPHA], io.dreg = w.st[ST_DREG], io.dregn = w.st[ST_DREGN];
     io.mu0 = A.tune[0], io.sfloor = A.tune[1];
+    io.atr = w.st[ST_ATR], io.mut = fmax(w.st[ST_SIGMU], 1e-3 * w.st[ST_MU]);
+    const double* dvec = PASS == PASS_KMUL_A ? w.dxa : (use_dx2 ? w.dx2 : w.dx);
     io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 0, io.vmin = 1e300;
     double pin_viol = 0;
     const double ra = radius[a];
@@ -328,7 +360,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
         for (int k = 0; k < 3; ++k) {
             xa[k] = ctrl[((size_t)a * 3 + k) * oq + j6];
             da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
-            dd[k] = need_dd ? (PASS == PASS_KMUL_A ? w.dxa : w.dx)[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            dd[k] = need_dd ? dvec[((size_t)a * 3 + k) * oq + j6] : 0.0;
         }
         double Sm[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
         if (ch == 0) {  // bound rows
@@ -363,8 +395,9 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                         }
                         continue;
                     }
-                    row_op<PASS>(slack, sg * da[k], sg * dd[k], s, z, io, 1.0, wgt, v, zo, sn, zn);
+                    row_op<PASS>(slack, sg * da[k], sg * dd[k], s, z, io, 1.0, wgt, v, zo, sn, zn, use_t ? w.tb[r] : 0.0);
                     if (wr_sz) bs2[r] = sn, bz2[r] = zn;
+                    if (gond) w.tb[r] = sn;
                     if (accum) {
                         const int dg = k == 0 ? 0 : (k == 1 ? 3 : 5);
                         if (build) {
@@ -401,7 +434,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                 gab = a_lo ? n0 * (da[0] - f0) + n1 * (da[1] - f1) + n2 * (da[2] - f2) : n0 * (f0 - da[0]) + n1 * (f1 - da[1]) + n2 * (f2 - da[2]);
             }
             if (need_dd) {
-                const double* dxp = PASS == PASS_KMUL_A ? w.dxa : w.dx;
+                const double* dxp = dvec;
                 const double f0 = dxp[((size_t)b * 3 + 0) * oq + j6], f1 = dxp[((size_t)b * 3 + 1) * oq + j6], f2 = dxp[((size_t)b * 3 + 2) * oq + j6];
                 gdb = a_lo ? n0 * (dd[0] - f0) + n1 * (dd[1] - f1) + n2 * (dd[2] - f2) : n0 * (f0 - dd[0]) + n1 * (f1 - dd[1]) + n2 * (f2 - dd[2]);
             }
@@ -423,8 +456,9 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
                 }
                 continue;
             }
-            row_op<PASS>(slack, gab, gdb, s, z, io, a_lo ? 1.0 : 0.0, wgt, v, zo, sn, zn);
+            row_op<PASS>(slack, gab, gdb, s, z, io, a_lo ? 1.0 : 0.0, wgt, v, zo, sn, zn, use_t ? w.tp[r] : 0.0);
             if (wr_sz && a_lo) ps2[r] = sn, pz2[r] = zn;
+            if (gond && a_lo) w.tp[r] = sn;
             if (accum) {
                 const double sg = a_lo ? 1.0 : -1.0;
                 if (build) {
@@ -473,7 +507,7 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
             red_slot(w, A.L, RS_AFF, 0)[wg] = vm, red_slot(w, A.L, RS_AFF, 1)[wg] = q0;
             red_slot(w, A.L, RS_AFF, 2)[wg] = q1, red_slot(w, A.L, RS_AFF, 3)[wg] = q2;
         }
-    } else if (PASS == PASS_STEP) {
+    } else if (PASS == PASS_STEP || PASS == PASS_STEPG) {
         const double vm = block_reduce(io.vmax, 1, red);
         if (tid == 0) red_slot(w, A.L, RS_STEP, 0)[wg] = vm;
     } else if (PASS == PASS_VERIFY) {
@@ -492,7 +526,8 @@ __device__ __forceinline__ double acc_sum(const Ws& w, const JDims& d, int e, si
 // ------------------------------------------------------------------------------------------------------------------------
 // reduced-space right-hand sides.  One thread per (knot j, agent a, dim k):
 //   post<0>: rbase = -F'(2Qx + G'z), rhs = rbase + F'(G'v) (predictor), partials of max|rbase| and max|2Qx + G'z|
-//   post<1>: rhs = rbase + F'(part1 - sigma mu * part2)   (corrector; both parts were accumulated by the AFF sweep)
+//   post<1>: rhs = rbase + F'(part1 - sigma mu * part2)   (corrector; both parts were accumulated by the AFF sweep); kept in rhsc
+//   post<2>: rhs = rhsc + F'(G'v)   (centrality corrector: v = -W t / z from the GOND sweep)
 // ------------------------------------------------------------------------------------------------------------------------
 template <int CORR>
 __global__ __launch_bounds__(256) void jq_post(JArgs A) {
@@ -501,6 +536,7 @@ __global__ __launch_bounds__(256) void jq_post(JArgs A) {
     const Ws w = carve(A, mission);
     __shared__ double red[8];
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (CORR == 2 && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
     const int oq = d.oq, nu = 3 * N;
@@ -517,7 +553,9 @@ __global__ __launch_bounds__(256) void jq_post(JArgs A) {
         for (int q = 0; q < 6; ++q) {
             const int j6 = 6 * (j - 1) + 3 + q;
             const size_t cp = (size_t)a * oq + j6;
-            if (CORR) {
+            if (CORR == 2) {
+                y[q] = acc_sum(w, d, k, cp);
+            } else if (CORR == 1) {
                 y[q] = acc_sum(w, d, k, cp) - sigma_mu * acc_sum(w, d, 3 + k, cp);
             } else {
                 const int m = j6 / 6, i = j6 % 6;
@@ -535,14 +573,18 @@ __global__ __launch_bounds__(256) void jq_post(JArgs A) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             double rb;
-            if (CORR)
+            if (CORR == 2)
+                rb = w.rhsc[o0 + e];
+            else if (CORR == 1)
                 rb = w.rbase[o0 + e];
             else {
                 rb = g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
                 w.rbase[o0 + e] = rb;
                 dmax = fmax(dmax, fabs(rb));
             }
-            w.rhs[o0 + e] = rb + y[3 + e] + L[0 + e] * y[0] + L[3 + e] * y[1] + L[6 + e] * y[2];
+            const double r = rb + y[3 + e] + L[0 + e] * y[0] + L[3 + e] * y[1] + L[6 + e] * y[2];
+            w.rhs[o0 + e] = r;
+            if (CORR == 1) w.rhsc[o0 + e] = r;
         }
     }
     if (!CORR) {
@@ -551,12 +593,13 @@ __global__ __launch_bounds__(256) void jq_post(JArgs A) {
     }
 }
 
-// dx[a][k][j6] = F du (du = the solution left in rhs); which: 0 -> dxa, 1 -> dx
+// dx[a][k][j6] = F du (du = the solution left in rhs); which: 0 -> dxa, 1 -> dx, 2 -> dx2
 __global__ __launch_bounds__(256) void jq_apply_F(JArgs A, int which) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (A.gond_only && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission];
     const JDims d = jdims(N, M);
     const int nu = 3 * N, it = blockIdx.x * 256 + threadIdx.x;
@@ -565,7 +608,7 @@ __global__ __launch_bounds__(256) void jq_apply_F(JArgs A, int which) {
     const double* uu = w.rhs + (size_t)(j - 1) * d.nkp + u * 3;
     const double* L = w.Lk + 9 * j;
     const double u0 = uu[0], u1 = uu[1], u2 = uu[2];
-    double* o = (which ? w.dx : w.dxa) + (size_t)u * d.oq + 6 * (j - 1) + 3;
+    double* o = (which == 2 ? w.dx2 : (which ? w.dx : w.dxa)) + (size_t)u * d.oq + 6 * (j - 1) + 3;
     o[0] = L[0] * u0 + L[1] * u1 + L[2] * u2;
     o[1] = L[3] * u0 + L[4] * u1 + L[5] * u2;
     o[2] = L[6] * u0 + L[7] * u1 + L[8] * u2;
@@ -585,6 +628,33 @@ __global__ __launch_bounds__(256) void jq_stepx(JArgs A) {
     ctrl[i] += (w.st[ST_ALPHA] - w.st[ST_APPLIED]) * w.dx[i];
 }
 
+// the safeguard of jq_ctrl(1) takes the last step back: x -= alpha dx (dx is still the direction of that step)
+__global__ __launch_bounds__(256) void jq_unstep(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_REVERT] != 1.0) return;
+    const int N = S.N, M = S.Mk[mission], MS = S.M;
+    const int nx = N * 3 * 6 * M, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nx) return;
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    ctrl[i] -= w.st[ST_ALPHA] * w.dx[i];
+}
+__global__ void jq_unstep_done(JArgs A) {
+    const Ws w = carve(A, blockIdx.x);
+    if (threadIdx.x == 0 && w.st[ST_REVERT] == 1.0) w.st[ST_REVERT] = 2.0;  // (taken back once; the record keeps that it happened)
+}
+
+// the centrality corrector was accepted: its direction becomes THE direction (the rows' shifts T stay in tb / tp, flagged by ST_GOK)
+__global__ __launch_bounds__(256) void jq_gcopy(JArgs A) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GOK] == 0.0) return;  // (ST_GOK lasts until the next iteration's step sweep)
+    const int nx = S.N * 3 * 6 * S.Mk[mission], i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nx) w.dx[i] = w.dx2[i];
+}
+
 // ---- iterative refinement of a Newton solve.  The substitutions multiply with explicit inverses: their residual is cond(K) eps, not eps
 // (the price of having no triangular solves), and with Newton weights of 1e9 the last interior-point iterations lose the dual residual
 // without it.  K du is formed matrix-free: K0 F du from the jerk Gram matrices, J'W J F du by a row sweep (PASS_KMUL).
@@ -597,6 +667,7 @@ __global__ __launch_bounds__(256) void jq_refine(JArgs A, int op, int which) {
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
     if (w.st[ST_NREF] <= (double)(op == 0 ? 0 : A.ref_step)) return;
+    if (A.gond_only && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission];
     const JDims d = jdims(N, M);
     const int oq = d.oq, nu = 3 * N, it = blockIdx.x * 256 + threadIdx.x;
@@ -618,7 +689,7 @@ __global__ __launch_bounds__(256) void jq_refine(JArgs A, int op, int which) {
         }
         return;
     }
-    const double* dxp = (which ? w.dx : w.dxa) + ((size_t)a * 3 + k) * oq;
+    const double* dxp = (which == 2 ? w.dx2 : (which ? w.dx : w.dxa)) + ((size_t)a * 3 + k) * oq;
     const double* L = w.Lk + 9 * j;
     double g[6];
 #pragma unroll
@@ -682,9 +753,24 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             // dual residual that RISES with the Newton weights (1e-9 .. 1e-5 once mu < 1e-10, even with two refinement steps per solve),
             // so going on only loses accuracy; what turns this iterate into the optimum is the active-set polish, not more iterations
             const bool ok = (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
-                            (pres < 1e-9 && dres < 1e-7 && mu < 1e-9);
+                            (pres < 1e-9 && dres < 1e-7 && mu < A.exit_mu);
             const bool polish_on = S.p.polish != 0;
-            if (ok) {
+            // SAFEGUARD.  Past mu ~ 1e-8 a step can cost the dual residual five orders of magnitude (explicit inverses at Newton weights
+            // of 1e9: 5e-9 -> 1e-5 -> 1e-2 in two iterations, after which the method crawls for a hundred iterations or never returns).
+            // If the iterate before the last step was acceptable and this one is not an exit and has lost the dual residual, the step is
+            // taken back (x -= alpha dx by jq_unstep, the old (s, z) are still in the other parity) and that iterate is the answer
+            // (final polish attempt, else unpolished with its own residuals).
+            const bool lost = !ok && st[ST_PACC] != 0.0 && (dres >= 1e-7 || dres > 100.0 * st[ST_PDRES]);
+            if (lost) {
+                st[ST_REVERT] = 1.0, st[ST_PAR] = 1.0 - st[ST_PAR];
+                st[ST_MU] = st[ST_PMU], st[ST_PRES] = st[ST_PPRES], st[ST_DRES] = st[ST_PDRES];
+                st[ST_KKT] = fmax(st[ST_PPRES], fmax(st[ST_PDRES], st[ST_PMU]));
+                st[ST_PACC] = 0.0;
+            } else {
+                st[ST_PACC] = (pres < 1e-9 && dres < 1e-7 && mu < 5e-8) ? 1.0 : 0.0;
+                st[ST_PMU] = mu, st[ST_PPRES] = pres, st[ST_PDRES] = dres;
+            }
+            if (ok || lost) {
                 if (polish_on)
                     st[ST_GO] = 1.0, st[ST_FINAL] = 1.0;  // final crossover; the mission stays "running" until it has been tried
                 else
@@ -713,7 +799,20 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
     } else if (which == 3) {
         if (st[ST_RETRY] != 0.0) return;
         const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, A.tune[4], red);
-        if (tid == 0) st[ST_ALPHA] = A.tune[4] / vm, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
+        if (tid == 0) {
+            const double ap = A.tune[4] / vm;
+            st[ST_ALPHA] = ap, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
+            // centrality corrector (first == 1: enabled): tried whenever the Mehrotra direction stops short
+            st[ST_GOK] = 0.0, st[ST_AP] = ap, st[ST_ATR] = fmin(1.0, ap + 0.3), st[ST_GACT] = (first && ap < 0.9) ? 1.0 : 0.0;
+        }
+    } else if (which == 5) {  // after STEPG: keep the corrected direction if the step grows by a tenth of what was asked for
+        if (st[ST_RETRY] != 0.0 || st[ST_GACT] == 0.0) return;
+        const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, A.tune[4], red);
+        if (tid == 0) {
+            const double an = A.tune[4] / vm;
+            if (an >= st[ST_AP] + 0.03) st[ST_GOK] = 1.0, st[ST_ALPHA] = an;
+            st[ST_GACT] = 0.0;
+        }
     } else if (which == 4) {
         if (A.retry_only && st[ST_RETRY] == 0.0) return;
         const double gap = red_final(red_slot(w, A.L, RS_BUILD, 0), nsw, 0, 0.0, red);
@@ -913,63 +1012,6 @@ __device__ __forceinline__ bool gj16_lds(double* D, int lane) {
         for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = v[q];
         JQ_WSYNC();
     }
-    return ok;
-}
-// The same Gauss-Jordan inverse with the matrix in REGISTERS for all sixteen column steps (lane (r, g) owns D[r][4g .. 4g+3]): the pivot is a
-// v_readlane (scalar), the pivot row's segment comes from lane (c, g) of the lane's own row of sixteen by DPP row_newbcast, the row's entry
-// in the pivot column from the row of sixteen g0 = c / 4 by the gfx950 lane swaps (v_permlane32_swap + v_permlane16_swap: two VALU
-// operations per dword instead of an LDS round trip with its write, fence and read).  In / out through LDS as gj16_lds.
-template <int DPP_CTRL>
-__device__ __forceinline__ double dpp_bcast(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), DPP_CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), DPP_CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-template <int G0>
-__device__ __forceinline__ unsigned rows_bcast32(unsigned x) {  // every row of sixteen lanes receives row G0, position by position
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 a = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // a[0] = rows (0, 1, 0, 1), a[1] = rows (2, 3, 2, 3)
-    const unsigned y = G0 < 2 ? a[0] : a[1];
-    const u2 b = __builtin_amdgcn_permlane16_swap(y, y, false, false);  // b[0] = the even row of y four times, b[1] = the odd one
-    return (G0 & 1) ? b[1] : b[0];
-}
-template <int G0>
-__device__ __forceinline__ double rows_bcast(double v) {
-    return __hiloint2double((int)rows_bcast32<G0>((unsigned)__double2hiint(v)), (int)rows_bcast32<G0>((unsigned)__double2loint(v)));
-}
-template <int C>
-__device__ __forceinline__ void gj16_step(double (&v)[4], int r, int g, bool& ok) {
-    constexpr int G0 = C / 4, Q0 = C % 4;
-    const double p = rl(v[Q0], C + 16 * G0);
-    const double f = rows_bcast<G0>(v[Q0]);
-    double pr[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pr[q] = dpp_bcast<0x150 + C>(v[q]);
-    ok = ok && (p > 0.0);
-    const double ip = fast_rcp(p), fi = f * ip;
-    if (r == C) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = pr[q] * ip;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] -= fi * pr[q];
-    }
-    if (g == G0) v[Q0] = r == C ? ip : -fi;
-}
-__device__ __forceinline__ bool gj16_reg(double* D, int lane) {
-    const int r = lane & 15, g = lane >> 4;
-    double v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = D[r * 18 + 4 * g + q];
-    bool ok = true;
-    gj16_step<0>(v, r, g, ok), gj16_step<1>(v, r, g, ok), gj16_step<2>(v, r, g, ok), gj16_step<3>(v, r, g, ok);
-    gj16_step<4>(v, r, g, ok), gj16_step<5>(v, r, g, ok), gj16_step<6>(v, r, g, ok), gj16_step<7>(v, r, g, ok);
-    gj16_step<8>(v, r, g, ok), gj16_step<9>(v, r, g, ok), gj16_step<10>(v, r, g, ok), gj16_step<11>(v, r, g, ok);
-    gj16_step<12>(v, r, g, ok), gj16_step<13>(v, r, g, ok), gj16_step<14>(v, r, g, ok), gj16_step<15>(v, r, g, ok);
-    JQ_WSYNC();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = v[q];
-    JQ_WSYNC();
     return ok;
 }
 __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
@@ -1301,6 +1343,7 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
     const Chain c = chain_step(d, chain, s, mode == 1 || mode == 3);
     if (!c.active || (int)blockIdx.x * 16 >= d.nkp) return;
     if (w.st[ST_NREF] < (double)A.ref_gate) return;  // a refinement pass this mission did not ask for
+    if (A.gond_only && w.st[ST_GACT] == 0.0) return;
     if (mode == 3) {  // x_m: wv -> rhs (the middle step cannot write rhs itself: the other slabs of its launch still read r_m there)
         const int row = blockIdx.x * 16 + (tid >> 4);
         if ((tid & 15) == 0 && row < d.nk) w.rhs[(size_t)c.jj * d.nkp + row] = w.wv[(size_t)c.jj * d.nkp + row];
@@ -1478,6 +1521,7 @@ JLayout jq_layout(int N, int MS) {
     L.o_scr = take((size_t)2 * d.nkp * d.nkp);
     L.o_inv = take((size_t)d.nj * d.nkp * d.nkp);
     L.o_pol = take(pol_layout(N, MS).total);
+    L.o_rhsc = take((size_t)d.nj * d.nkp), L.o_dx2 = take(3 * ncp), L.o_tb = take(6 * ncp), L.o_tp = take(nrow);
     L.stride = o;
     return L;
 }
@@ -1493,7 +1537,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     A.S = s, A.ws = (double*)ws, A.L = jq_layout(s.N, s.M);
     {
         const char* e = getenv("RBP_JQ_DREG");  // experiments: "mode,scale,max"
-        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0;
+        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0, A.gond_only = 0;
         if (e) sscanf(e, "%d,%lf,%lf", &A.dreg_mode, &A.dreg_scale, &A.dreg_max);
         A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
         A.pol_lh_early = 60, A.pol_lh_final = 160;
@@ -1531,8 +1575,10 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             A.ref_step = rs;
             if (which_out == 0)
                 JQ_LAUNCH(jq_sweep<PASS_KMUL_A>, dim3(nsw, K), 0, A);
-            else
+            else if (which_out == 1)
                 JQ_LAUNCH(jq_sweep<PASS_KMUL_D>, dim3(nsw, K), 0, A);
+            else
+                JQ_LAUNCH(jq_sweep<PASS_KMUL_G>, dim3(nsw, K), 0, A);
             JQ_LAUNCH(jq_refine, dim3(npost, K), 0, A, 1, which_out);
             A.ref_gate = rs + 1;
             substitute(which_out);
@@ -1547,6 +1593,8 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // CU, the pivot inverse in a launch of its own)
     const char* be = getenv("RBP_JQ_SCHED");  // "look" | "bulk" (A/B runs: tools/joint_sched_ab.sh)
     const bool bulk = be ? be[0] == 'b' : K >= 8 && (size_t)K * 2 * ntri >= 1024;
+    const int gondzio = getenv("RBP_JQ_GONDZIO") ? atoi(getenv("RBP_JQ_GONDZIO")) != 0 : 1;
+    A.exit_mu = getenv("RBP_JQ_EXITMU") ? atof(getenv("RBP_JQ_EXITMU")) : 1e-9;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
@@ -1650,6 +1698,8 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         if (it == 0) JQ_LAUNCH(jq_sweep<PASS_BUILD>, dim3(nsw, K), 0, A);
         JQ_LAUNCH(jq_post<0>, dim3(npost, K), 0, A);
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 1, (int)(it == 0));
+        JQ_LAUNCH(jq_unstep, dim3(nxblk, K), 0, A);
+        hipLaunchKernelGGL(jq_unstep_done, dim3(K), dim3(64), 0, st, A);
         // is any mission still running?  (one synchronisation per iteration)
         if (hipMemcpy2DAsync(state_h, sizeof(double) * ST_N, A.ws + L.o_state, L.stride * sizeof(double), sizeof(double) * ST_N, K,
                              hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1699,7 +1749,19 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jq_post<1>, dim3(npost, K), 0, A);
         solve(1);
         JQ_LAUNCH(jq_sweep<PASS_STEP>, dim3(nsw, K), 0, A);
-        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 3, 0);
+        JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 3, gondzio);
+        if (gondzio) {
+            // one centrality corrector on the factorisation already paid for: a sweep for the rows' target shifts, a solve, a sweep for
+            // the new step length (missions whose Mehrotra step is long enough skip all of it)
+            A.gond_only = 1;
+            JQ_LAUNCH(jq_sweep<PASS_GOND>, dim3(nsw, K), 0, A);
+            JQ_LAUNCH(jq_post<2>, dim3(npost, K), 0, A);
+            solve(2);
+            JQ_LAUNCH(jq_sweep<PASS_STEPG>, dim3(nsw, K), 0, A);
+            JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 5, 0);
+            JQ_LAUNCH(jq_gcopy, dim3(nxblk, K), 0, A);
+            A.gond_only = 0;
+        }
         JQ_LAUNCH(jq_stepx, dim3(nxblk, K), 0, A);
         JQ_LAUNCH(jq_sweep<PASS_UPBUILD>, dim3(nsw, K), 0, A);
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);

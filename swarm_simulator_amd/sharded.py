@@ -121,7 +121,12 @@ def gather_corridor_device(dist, arrs, n_agents, slices):
     t = torch.zeros(maxb, dtype=torch.uint8, device=mine.device)
     t[:mine.numel()] = mine
     out = torch.empty(world * maxb, dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(out, t)
+    try:
+        dist.all_gather_into_tensor(out, t)          # RCCL: one collective on the device buffers
+    except (RuntimeError, NotImplementedError):       # gloo (tests: two ranks on one GPU) has neither the flat form nor device all_gather
+        outs = [torch.empty(maxb, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, t.cpu())
+        out = torch.cat(outs).to(mine.device)
     for r in range(world):
         if r != rank:
             unpack_shard_device(arrs, out[r * maxb:r * maxb + lens[r]], slices[r], offs[r])

@@ -1,4 +1,6 @@
 """GPU: agent-sharded Corridor::update (rbp_corridor_update_range) and the 256-agent config C4 on one GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,42 @@ def test_device_side_exchange_of_shards(n_shards):
     assert np.array_equal(g.ctrl.view(np.uint64), full.ctrl.view(np.uint64)) and g.total_cost == full.total_cost
     for s in sessions:
         s.close()
+
+
+def test_two_rank_plan_sharded_device(tmp_path):
+    """plan_sharded_device with a real process group of two ranks (both on this one GPU, so the group is gloo: RCCL refuses two ranks on
+    one device; on a multi-GPU node the same code takes all_gather_into_tensor over RCCL): flag all_reduce, padded shard exchange between
+    the two sessions' HBM arrays, PLANNER stage on the completed corridor.  Every rank must return the unsharded plan bit for bit."""
+    import json, re, socket, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "s.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {root!r})
+        import numpy as np, torch
+        import torch.distributed as dist
+        from swarm_simulator_amd import host, planner
+        from swarm_simulator_amd.types import Param
+        from swarm_simulator_amd.sharded import plan_sharded_device
+        dist.init_process_group("gloo")
+        p = Param.test_sweep()
+        m = host.load_mission("mission_16agents_15.json")
+        w = host.load_world("map12.bt", p)
+        init = host.ecbs_plan(w, m, p)
+        full = init.clone_inputs()
+        assert planner.Corridor(w, m, p).update(False, full) and planner.RBPPlanner(m, p).update(False, full)
+        mine = init.clone_inputs()
+        ok, err = plan_sharded_device(w, m, p, mine, dist, "cuda:0")
+        same = bool(ok and np.array_equal(mine.sfc_box, full.sfc_box) and np.array_equal(mine.sfc_count, full.sfc_count)
+                    and np.array_equal(mine.rsfc_normal.view(np.uint32), full.rsfc_normal.view(np.uint32))
+                    and np.array_equal(mine.ctrl.view(np.uint64), full.ctrl.view(np.uint64)) and mine.total_cost == full.total_cost)
+        print(json.dumps({{"rank": dist.get_rank(), "same": same, "err": err}}))
+        dist.destroy_process_group()
+    """))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = str(sk.getsockname()[1]); sk.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [json.loads(t) for t in re.findall(r"\{[^{}]*\}", out.stdout)]
+    assert len(res) == 2 and all(r["same"] for r in res), res

@@ -1,5 +1,9 @@
 // Developer micro-benchmark (not product): the 64 x 64 pivot-tile inverse of the joint solver's sweep (kernels/jqp.hip inv64_lds), the
 // dependent chain of a lone joint mission.  One workgroup, 256 threads; times from the 100 MHz wall clock.
+// MI355X, round 4: inv64_lds 19.9 us, of which the four 16 x 16 Gauss-Jordan leaves 4 x 2.0 us (300 cycles per column step: the chain
+// pivot -> reciprocal (v_rcp_f64 + two Newton steps) -> multiplier -> update).  A leaf that keeps the matrix in registers (pivot row by DPP
+// row_newbcast, pivot column by v_permlane32_swap + v_permlane16_swap, no LDS in the loop) measured the same 1.97 us: the reciprocal
+// chain, not the data movement, is the leaf's time.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../swarm_simulator_amd/csrc/kernels -I../../include -o inv64 inv64.hip && ./inv64
 #include "../../swarm_simulator_amd/csrc/kernels/jqp.hip"
 #include <cstdio>
@@ -18,10 +22,7 @@ __global__ __launch_bounds__(256) void k_inv64(const double* A, double* out, lon
         for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = A[i];
         __syncthreads();
         const long long t0 = wall_clock64();
-        if (variant == 0)
-            inv64_lds(Am, &sc, &bad);
-        else
-            inv64_lds(Am, &sc, &bad);
+        inv64_lds(Am, &sc, &bad);
         __syncthreads();
         acc += wall_clock64() - t0;
     }
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void k_gj16(const double* A, double* out, long 
         for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = A[r * 64 + 4 * g + q];
         JQ_WSYNC();
         const long long t0 = wall_clock64();
-        ok = variant == 0 ? gj16_lds(D, lane) : gj16_reg(D, lane);
+        ok = gj16_lds(D, lane);
         JQ_WSYNC();
         acc += wall_clock64() - t0;
     }
@@ -50,13 +51,13 @@ int main() {
     std::vector<double> A(JTT), R(JTT);
     // SPD test matrix: diagonally dominant with decaying off-diagonals, condition ~1e6
     for (int i = 0; i < 64; ++i)
-        for (int j = 0; j < 64; ++j) A[i * 64 + j] = (i == j ? 1.0 + 1e-3 * i : 0.0) + 0.9 * std::exp(-0.05 * std::abs(i - j)) * std::cos(0.3 * (i + j));
+        for (int j = 0; j < 64; ++j) A[i * 64 + j] = (i == j ? 1.0 + 1e-3 * i : 0.0) + 0.9 * std::exp(-0.05 * std::abs(i - j));  // (exponential kernel: SPD)
     for (int i = 0; i < 64; ++i) A[i * 64 + i] += 3.0;
     double *dA, *dO;
     long long* dT;
     hipMalloc(&dA, JTT * 8), hipMalloc(&dO, JTT * 8), hipMalloc(&dT, 16);
     hipMemcpy(dA, A.data(), JTT * 8, hipMemcpyHostToDevice);
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 1; ++variant) {
         long long T[2];
         for (int pass = 0; pass < 2; ++pass) hipLaunchKernelGGL(k_inv64, dim3(1), dim3(256), 0, 0, dA, dO, dT, variant);
         hipMemcpy(T, dT, 16, hipMemcpyDeviceToHost), hipMemcpy(R.data(), dO, JTT * 8, hipMemcpyDeviceToHost);
