@@ -803,14 +803,14 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             const double ap = A.tune[4] / vm;
             st[ST_ALPHA] = ap, st[ST_APPLIED] = 0.0, st[ST_BT] = 0.0;
             // centrality corrector (first == 1: enabled): tried whenever the Mehrotra direction stops short
-            st[ST_GOK] = 0.0, st[ST_AP] = ap, st[ST_ATR] = fmin(1.0, ap + 0.3), st[ST_GACT] = (first && ap < 0.9) ? 1.0 : 0.0;
+            st[ST_GOK] = 0.0, st[ST_AP] = ap, st[ST_ATR] = fmin(1.0, ap + A.gond[0]), st[ST_GACT] = (first && ap < A.gond[2]) ? 1.0 : 0.0;
         }
     } else if (which == 5) {  // after STEPG: keep the corrected direction if the step grows by a tenth of what was asked for
         if (st[ST_RETRY] != 0.0 || st[ST_GACT] == 0.0) return;
         const double vm = red_final(red_slot(w, A.L, RS_STEP, 0), nsw, 1, A.tune[4], red);
         if (tid == 0) {
             const double an = A.tune[4] / vm;
-            if (an >= st[ST_AP] + 0.03) st[ST_GOK] = 1.0, st[ST_ALPHA] = an;
+            if (an >= st[ST_AP] + A.gond[1] * A.gond[0]) st[ST_GOK] = 1.0, st[ST_ALPHA] = an;
             st[ST_GACT] = 0.0;
         }
     } else if (which == 4) {
@@ -1594,6 +1594,8 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     const char* be = getenv("RBP_JQ_SCHED");  // "look" | "bulk" (A/B runs: tools/joint_sched_ab.sh)
     const bool bulk = be ? be[0] == 'b' : K >= 8 && (size_t)K * 2 * ntri >= 1024;
     const int gondzio = getenv("RBP_JQ_GONDZIO") ? atoi(getenv("RBP_JQ_GONDZIO")) != 0 : 1;
+    A.gond[0] = 0.3, A.gond[1] = 0.1, A.gond[2] = 0.9;
+    if (getenv("RBP_JQ_GOND")) sscanf(getenv("RBP_JQ_GOND"), "%lf,%lf,%lf", &A.gond[0], &A.gond[1], &A.gond[2]);  // experiments
     A.exit_mu = getenv("RBP_JQ_EXITMU") ? atof(getenv("RBP_JQ_EXITMU")) : 1e-9;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
