@@ -98,6 +98,33 @@ def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
             assert rep["forward_error"] < CTRL_TOL, tag
 
 
+@pytest.mark.parametrize("map_id", [41, 44])
+def test_joint_64_maps_that_lose_the_dual_residual(map_id, monkeypatch):
+    """maps 41 and 44 of the sweep: past mu ~ 1e-8 one interior-point step costs the dual residual five orders of magnitude (explicit
+    inverses at Newton weights of 1e9) and, depending on last-bit differences of the build, the method then crawled for a hundred
+    iterations or ran out of rounds.  The safeguard of jq_ctrl(1) takes that step back and answers with the iterate before it: the
+    mission is solved within a normal iteration count, feasible, with a small reported KKT residual (polished or not)."""
+    p, m, w, init = _inputs(64, map_id)
+    g = _plan(p, m, w, init, True, monkeypatch)
+    assert g.qp_solves == 1 and g.qp_iterations <= 60
+    assert g.kkt_max < 2e-7
+    obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+    assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+    assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
+
+
+def test_joint_centrality_corrector_saves_iterations(monkeypatch):
+    """one Gondzio corrector per iteration (on by default; RBP_JQ_GONDZIO=0 switches it off): fewer iterations, the same optimum"""
+    p, m, w, init = _inputs(64, 3)
+    monkeypatch.setenv("RBP_JQ_GONDZIO", "0")
+    plain = _plan(p, m, w, init, True, monkeypatch)
+    monkeypatch.setenv("RBP_JQ_GONDZIO", "1")
+    corr = _plan(p, m, w, init, True, monkeypatch)
+    assert corr.qp_iterations < plain.qp_iterations
+    assert corr.qp_unpolished == 0 and plain.qp_unpolished == 0
+    assert np.abs(corr.ctrl - plain.ctrl).max() < CTRL_TOL
+
+
 def test_joint_256_agents_solved_and_feasible(monkeypatch):
     """BASELINE config C4's mission as ONE joint QP: knot blocks of order 2304 (no mission file of this size exists upstream:
     tools/make_mission_256.py).  No oracle can follow (dense LU of order ~1e5): the reference's constraint sets judge the answer."""
