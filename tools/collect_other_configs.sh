@@ -13,5 +13,6 @@ run python bench.py --agents 16 --joint --missions-per-gpu 250 --steps 2 --no-cp
 run python bench.py --missions-per-gpu 50 --no-cpu-baseline
 run python bench.py --missions-per-gpu 250 --no-cpu-baseline
 run python bench.py --missions-per-gpu 500 --no-cpu-baseline
-run python tools/gpu_joint.py 64 3 --no-oracle
+run python bench.py --config c4 --joint --no-cpu-baseline
+run python bench.py --agents 64 --joint --missions-per-gpu 50 --steps 2 --no-cpu-baseline
 cat $L

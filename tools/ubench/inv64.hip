@@ -3,7 +3,8 @@
 // MI355X, round 4: inv64_lds 19.9 us, of which the four 16 x 16 Gauss-Jordan leaves 4 x 2.0 us (300 cycles per column step: the chain
 // pivot -> reciprocal (v_rcp_f64 + two Newton steps) -> multiplier -> update).  A leaf that keeps the matrix in registers (pivot row by DPP
 // row_newbcast, pivot column by v_permlane32_swap + v_permlane16_swap, no LDS in the loop) measured the same 1.97 us: the reciprocal
-// chain, not the data movement, is the leaf's time.
+// chain, not the data movement, is the leaf's time.  Fetching the operands of a wave's three trailing products together and interleaving
+// their MFMA chains made the tile inverse SLOWER (21.7 us against 19.8 us on the same matrix): not kept either.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I../../swarm_simulator_amd/csrc/kernels -I../../include -o inv64 inv64.hip && ./inv64
 #include "../../swarm_simulator_amd/csrc/kernels/jqp.hip"
 #include <cstdio>
