@@ -21,6 +21,7 @@ struct JArgs {
     int ref_step;   // which refinement step of a Newton solve the launch belongs to (kernels of step r skip missions with ST_NREF <= r)
     int retry_only; // launches that repeat a refused step: only missions with ST_RETRY set take part
     int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
+    int trace;      // RBP_JOINT_TRACE: device-side diagnostics of the polish's acceptance test
     int gond_only;  // launches of the centrality corrector: only missions with ST_GACT set take part
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;

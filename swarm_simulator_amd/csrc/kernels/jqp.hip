@@ -1611,6 +1611,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         }
     };
     const bool trace = getenv("RBP_JOINT_TRACE") != nullptr;
+    A.trace = trace ? 1 : 0;
     // ---- active-set polish of the missions whose control kernel asked for it (jqp_polish.inc); host-driven state machine, one
     // synchronisation per stage
     const PolLayout PL = pol_layout(N, s.M);
