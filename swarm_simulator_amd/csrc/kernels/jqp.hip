@@ -1659,6 +1659,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                 JQ_LAUNCH(jp_sort, dim3((ncmax + 255) / 256, K), 0, A);
                 JQ_LAUNCH(jp_sort_fin, dim3(K), 0, A);
                 JQ_LAUNCH(jp_S, dim3((unsigned)(((size_t)nc_max * nc_max + 255) / 256), K), 0, A);
+                JQ_LAUNCH(jp_twin, dim3((nc_max + 255) / 256, K), 0, A);
                 JQ_LAUNCH(jp_bpp, dim3(K), 0, A, 0);
             } else if (any_bpp) {
                 if (nblk_max > 0) {
