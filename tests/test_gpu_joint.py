@@ -155,6 +155,26 @@ def test_joint_256_agents_solved_and_feasible(monkeypatch):
             assert rep["stationarity"] < 1e-5 and rep["complementarity"] < 1e-8, tag
 
 
+def test_joint_64_session_of_six_maps_is_polished(monkeypatch):
+    """six 64-agent joint missions in one session (maps 1..6): every one ends as the KKT-certified optimum of the active-set polish.  Before
+    the polish knew about TWINS (the same reduced constraint written twice: last control point of a segment = first of the next under a
+    shared box face; jp_twin in kernels/jqp_polish.inc) two of these six were refused."""
+    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+    p = Param.test_sweep(sequential=False)
+    m = host.load_mission("mission_64agents_15.json")
+    worlds = [host.load_world(f"map{i}.bt", p) for i in range(1, 7)]
+    plans = [host.ecbs_plan(w, m, p).clone_inputs() for w in worlds]
+    sess = planner.Session(worlds, [m] * len(worlds), p, plans)
+    sess.run(A.RBP_STAGE_ALL)
+    assert sess.download() == [0] * len(worlds)
+    sess.close()
+    for g in plans:
+        assert g.qp_solves == 1 and g.qp_unpolished == 0 and g.kkt_max < 1e-9
+        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
+        assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
+
+
 def test_joint_session_matches_one_mission_calls_and_repeats(monkeypatch):
     monkeypatch.setenv("RBP_JOINT_WIDE", "1")
     p = Param.test_sweep(sequential=False)
