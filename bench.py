@@ -390,7 +390,7 @@ def main():
         except Exception:
             pass
         sfc_bytes = 4.0 * ct["sfc_samples"]
-        joint_wide = args.joint and N > 32 and os.environ.get("RBP_JOINT_WIDE", "1") != "0"
+        joint_wide = args.joint and (N >= 16 or os.environ.get("RBP_JOINT_WIDE") == "1") and os.environ.get("RBP_JOINT_WIDE", "1") != "0"
         out = {
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,

@@ -146,7 +146,7 @@ int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_p
  * swarm_traj_planner_rbp_test_all.cpp:49-103).  `run` only enqueues kernels on `stream`
  * (a hipStream_t passed as void*; NULL = default stream) and never synchronises -- with ONE exception: the PLANNER stage of a
  * non-sequential plan (plan/sequential = false, the reference's code default param.hpp:67: one joint QP over all agents,
- * rbp_planner.hpp:857-859) with more than 32 agents runs on the grid-wide solver (kernels/jqp.hip: a launch per phase of the
+ * rbp_planner.hpp:857-859) with 16 agents or more runs on the grid-wide solver (kernels/jqp.hip: a launch per phase of the
  * interior-point method over all CUs), whose host loop learns once per iteration whether any mission is still running: that
  * `run` SYNCHRONISES `stream` before it returns.  RBP_JOINT_WIDE=0 / 1 forces the one-workgroup kernel (<= 64 agents, no
  * synchronisation) / the grid-wide solver. */

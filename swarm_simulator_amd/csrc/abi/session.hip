@@ -171,12 +171,15 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     // ... and so does a mission with more than QP_MAX_M segments: the factor chains' LDS progress words sit behind 64 per-step
     // assembly counters (twisted_factor in kernels/qp.hip), one per step of the longer half chain, i.e. M - 1 <= 127 knots
     // The joint QP of a mission (plan/sequential = false: one batch of all N agents) is spread over the whole chip by kernels/jqp.hip
-    // when it is wide enough to pay for a launch per phase (default: more than 32 agents, i.e. knot blocks of order > 288; RBP_JOINT_WIDE
-    // = 0 / 1 forces the one-workgroup / the grid-wide solver).  It has no limit on N.
+    // when it is wide enough to pay for a launch per phase (default: 16 agents or more, i.e. knot blocks of order >= 144; RBP_JOINT_WIDE
+    // = 0 / 1 forces the one-workgroup / the grid-wide solver).  Measured (tools/gpu_joint_sweep.py, one mission / 250 / 1000 resident):
+    // 16 agents 0.067 s against 0.283 s, 9.2 k against 8.0 k, 11.2 k against 7.4 k agent-trajectories/s; 32 agents 0.105 s against 1.6 s,
+    // and the one-workgroup polish (<= 256 candidate rows) accepts none of the 50 maps there; 8 agents: 0.038 s against 0.062 s alone but
+    // 10.6 k against 18.1 k at 250 resident -- below 16 agents a workgroup per mission stays.  It has no limit on N.
     bool joint_wide = false;
     if (!param->sequential && biter > 0 && N >= 2) {
         const char* e = getenv("RBP_JOINT_WIDE");
-        joint_wide = e ? e[0] == '1' : N > 32;
+        joint_wide = e ? e[0] == '1' : N >= 16;
     }
     const bool planner_ok = joint_wide || (!(biter > 0 && bs > planner_max_batch()) && M <= QP_MAX_M);
 
