@@ -263,10 +263,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE.json configuration shortcut (sets the flags below)")
     ap.add_argument("--agents", type=int, default=64, help="mission_<N>agents_15.json (64 = headline, 16 = C2)")
-    ap.add_argument("--missions-per-gpu", type=int, default=2000,
+    ap.add_argument("--missions-per-gpu", type=int, default=None,
                     help="missions resident per step on each GPU: 2000 = forty passes of the reference's 50-map sweep (one "
                          "workgroup per mission, two resident per CU, the rest handed out by the dispatcher as slots free up: "
-                         "four rounds keep the tail short); 50 = exactly one sweep")
+                         "four rounds keep the tail short); 50 = exactly one sweep.  Default 2000; with --joint at 16 agents or more 200 "
+                         "(the grid-wide joint solver keeps every knot's explicit inverse: ~0.35 GB of workspace per 64-agent mission)")
     ap.add_argument("--batch-size", type=int, default=4, help="plan/batch_size (4 = plan_rbp_test.launch; 8 = BASELINE config C5)")
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
@@ -278,6 +279,8 @@ def main():
     if args.config:
         for k, v in CONFIGS[args.config].items():
             setattr(args, k, v)
+    if args.missions_per_gpu is None:
+        args.missions_per_gpu = 200 if (args.joint and args.agents >= 16) else 2000
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args.gpus))
