@@ -1,12 +1,12 @@
 """Golden vectors of the JOINT QP (plan/sequential = false, the reference's code default: param.hpp:67, rbp_planner.hpp:857-859) at 32 and 64
-agents: tests/golden/joint32_map7.npz, joint64_map3.npz.
+agents: tests/golden/joint32_map7.npz, joint32_map21.npz, joint64_map3.npz, joint64_map12.npz, joint64_map30.npz.
 
 The oracle's joint solve takes 26 s (32 agents) / 300 s (64 agents) on one core, too long for the test suites, so its answer is committed:
 control points of the certified optimum (oracle_qp_report: polished, stationarity < 1e-10), the objective, and a hash of the inputs the
 GPU test rebuilds (mission file, map, the repository's ECBS initTraj).  PARITY UNPINNED applies as for every oracle vector
 (oracle/README.md).
 
-Run from the repo root:   python tests/golden/make_joint_golden.py [32|64 ...]
+Run from the repo root:   python tests/golden/make_joint_golden.py [agents:map ...]      (default: every case below)
 """
 import hashlib
 import os
@@ -22,7 +22,7 @@ from swarm_simulator_amd.types import Param  # noqa: E402
 from tests import oracle_lib as O  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-CASES = {32: 7, 64: 3}
+CASES = [(32, 7), (32, 21), (64, 3), (64, 12), (64, 30)]
 
 
 def make(n, map_id):
@@ -42,5 +42,5 @@ def make(n, map_id):
 
 
 if __name__ == "__main__":
-    for n in ([int(a) for a in sys.argv[1:]] or sorted(CASES)):
-        make(n, CASES[n])
+    for n, map_id in ([tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or CASES):
+        make(n, map_id)

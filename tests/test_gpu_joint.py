@@ -3,7 +3,7 @@ Needs an MI355X.
 
 * 8 / 16 agents: grid-wide solver == one-workgroup solver == oracle within CTRL_TOL (three solvers, two of them sharing no linear
   algebra: tile-sweep inverses + block principal pivoting here, LDL' chains + Lawson-Hanson in kernels/qp.hip);
-* 32 / 64 agents: against the committed oracle vectors tests/golden/joint32_map7.npz / joint64_map3.npz (the oracle needs 26 s / 300 s
+* 32 / 64 agents: against the committed oracle vectors tests/golden/joint32_map{7,21}.npz / joint64_map{3,12,30}.npz (the oracle needs 26 s / 300 s
   on one core: tests/golden/make_joint_golden.py); 64 agents additionally certified by the independent numpy restatement on a sub-block
   of the QP (rows and variables of eight agents, everything else fixed at the answer);
 * 256 agents (BASELINE config C4's mission, joint): solved, every constraint set of the reference satisfied;
@@ -79,7 +79,7 @@ def test_grid_wide_vs_one_workgroup_vs_oracle(n, map_id, monkeypatch):
     assert np.abs(wide.ctrl - one.ctrl).max() < CTRL_TOL
 
 
-@pytest.mark.parametrize("n,map_id", [(32, 7), (64, 3)])
+@pytest.mark.parametrize("n,map_id", [(32, 7), (32, 21), (64, 3), (64, 12), (64, 30)])
 def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
     gold = np.load(os.path.join(GOLDEN, f"joint{n}_map{map_id}.npz"))
     p, m, w, init = _inputs(n, map_id)
@@ -91,7 +91,7 @@ def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
     assert abs(float(gold["total_cost"]) - g.total_cost) <= 1e-8 * max(1.0, abs(g.total_cost))
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
-    if n == 64:
+    if n == 64 and map_id == 3:
         for rep in _certify_sub_blocks(p, m, w, init, g, [0, 3, 7]):
             tag = f"agents {8 * rep['batch']}..: " + ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
             assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
