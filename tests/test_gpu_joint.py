@@ -175,6 +175,42 @@ def test_joint_64_session_of_six_maps_is_polished(monkeypatch):
         assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
 
 
+def test_joint_64_whole_sweep_against_the_oracle(monkeypatch):
+    """all 50 maps of the reference's sweep as 64-agent joint QPs in ONE session, against the oracle's committed answers
+    (tests/golden/joint64_sweep.npz: objective of every map and the control points of agents 0, 21, 42, 63; the oracle needs 5.5 min per map,
+    tests/golden/make_joint_sweep_golden.py).  Where the polish was accepted the GPU's control points are within CTRL_TOL of the oracle's
+    certified optimum and the objectives agree to 1e-8; where it was refused the answer is the interior-point iterate with its reported
+    residual: feasible, objective within 1e-4 relative.  At least 40 of the 50 maps must be polished (44 when this was written)."""
+    gold = np.load(os.path.join(GOLDEN, "joint64_sweep.npz"))
+    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+    p = Param.test_sweep(sequential=False)
+    m = host.load_mission("mission_64agents_15.json")
+    worlds = [host.load_world(f"map{i}.bt", p) for i in range(1, 51)]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+    for i, init in enumerate(inits):
+        assert hashlib.sha256(np.ascontiguousarray(init.init_traj).tobytes()).hexdigest() == str(gold["init_traj_sha256"][i]), f"map{i + 1}"
+    plans = [g.clone_inputs() for g in inits]
+    sess = planner.Session(worlds, [m] * 50, p, plans)
+    sess.run(A.RBP_STAGE_ALL)
+    assert sess.download() == [0] * 50
+    sess.close()
+    agents = [int(a) for a in gold["agents"]]
+    n_pol = 0
+    for i, g in enumerate(plans):
+        assert int(gold["rc"][i]) == 0 and g.M == int(gold["M"][i]), f"map{i + 1}"
+        ref_ctrl = gold["ctrl"][i][:, :, :6 * g.M]
+        err = np.abs(ref_ctrl - g.ctrl[agents]).max()
+        rel = abs(float(gold["cost"][i]) - g.total_cost) / max(1.0, abs(g.total_cost))
+        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL, f"map{i + 1}"
+        if g.qp_unpolished == 0 and int(gold["polished"][i]) == 1:
+            n_pol += 1
+            assert err < CTRL_TOL and rel < 1e-8, f"map{i + 1}: ctrl {err:.3g} cost {rel:.3g}"
+        else:
+            assert rel < 1e-4 and g.kkt_max < 2e-7, f"map{i + 1}: unpolished, cost {rel:.3g} kkt {g.kkt_max:.3g}"
+    assert n_pol >= 40, n_pol
+
+
 def test_joint_session_matches_one_mission_calls_and_repeats(monkeypatch):
     monkeypatch.setenv("RBP_JOINT_WIDE", "1")
     p = Param.test_sweep(sequential=False)
