@@ -27,6 +27,7 @@ struct JArgs {
     double dreg_scale, dreg_max;
     double gond[3];  // centrality corrector: extra step length asked for, share of it that must be gained, step length below which it is tried
     double early_mu[2];  // complementarity below which the first / the second early polish attempt is made
+    double pol_tau;  // polish: a pivot of S_AA below pol_tau x the row's own diagonal marks a row that depends on the rows before it (deleted from that solve)
     double exit_mu;  // third exit of the interior-point loop: pres < 1e-9, dres < 1e-7, mu < exit_mu
     double pol_lh_early, pol_lh_final;  // block Lawson-Hanson rounds allowed in an early / the final polish attempt
     double tune[5];  // mu0, slack floor, centring exponent, neighbourhood gamma, step fraction

@@ -866,6 +866,7 @@ struct SweepCtx {
     double* Pn;         // ... of step k + 1 (look-ahead)
     double* Y;          // panel
     double* bad;        // counter of non-positive pivots
+    const double* G;    // polish (kind 1): the matrix before the sweep (tile-major): its diagonal scales the deletion threshold; else nullptr
 };
 __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const JDims& d, int kind, int s, int mid, int k, int chain);
 
@@ -985,7 +986,12 @@ struct InvScratch {
 // D[r][4g .. 4g+3] in registers and publishes them after every column step; what a step needs from other lanes -- the pivot, the
 // pivot row's segment, the row's entry in the pivot column -- are same-address LDS reads (broadcasts: ~7 cycles per 8 bytes, no
 // v_readlane chains).  LDS serves a wave's operations in order, so a step's reads see the previous step's writes.
-__device__ __forceinline__ bool gj16_lds(double* D, int lane) {
+// thr (or nullptr): per column, the pivot size at or below which the row is DELETED from the solve instead of eliminated: row and column
+// become zero, i.e. the result is the inverse of the matrix without that row, with a zero row and column in its place.  The polish uses it
+// for active rows that are linear combinations of the rows before them (five control points around a knot are functions of three
+// variables: a trajectory that runs along a box face makes four or five bound rows of one agent and axis active at once); everything
+// downstream of a zero column of the pivot inverse -- panel, update, the other sub-tiles -- stays zero by the sweep's own algebra.
+__device__ __forceinline__ bool gj16_lds(double* D, int lane, const double* thr = nullptr) {
     const int r = lane & 15, g = lane >> 4;
     double v[4];
 #pragma unroll
@@ -997,16 +1003,24 @@ __device__ __forceinline__ bool gj16_lds(double* D, int lane) {
         double pr[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pr[q] = D[c * 18 + 4 * g + q];
-        ok = ok && (p > 0.0);
-        const double ip = fast_rcp(p), fi = f * ip;
-        if (r == c) {
+        if (thr && p <= thr[c]) {  // (wave-uniform)
+            if (r == c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = pr[q] * ip;
+                for (int q = 0; q < 4; ++q) v[q] = 0.0;
+            }
+            if (g == c / 4) v[c % 4] = 0.0;
         } else {
+            ok = ok && (p > 0.0);
+            const double ip = fast_rcp(p), fi = f * ip;
+            if (r == c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] -= fi * pr[q];
+                for (int q = 0; q < 4; ++q) v[q] = pr[q] * ip;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] -= fi * pr[q];
+            }
+            if (g == c / 4) v[c % 4] = r == c ? ip : -fi;
         }
-        if (g == c / 4) v[c % 4] = r == c ? ip : -fi;
         JQ_WSYNC();
 #pragma unroll
         for (int q = 0; q < 4; ++q) D[r * 18 + 4 * g + q] = v[q];
@@ -1014,7 +1028,7 @@ __device__ __forceinline__ bool gj16_lds(double* D, int lane) {
     }
     return ok;
 }
-__device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
+__device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* thr = nullptr) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     for (int kk = 0; kk < 4; ++kk) {
         // every wave inverts its own copy of the diagonal sub-tile (no barrier between the inversion and the wave's panel product)
@@ -1022,7 +1036,7 @@ __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) Pi[li * 18 + 4 * lg + q] = Am[(16 * kk + li) * LDA + 16 * kk + 4 * lg + q];
         JQ_WSYNC();
-        const bool okp = gj16_lds(Pi, lane);
+        const bool okp = gj16_lds(Pi, lane, thr ? thr + 16 * kk : nullptr);
         if (!okp && tid == 0) *bad = 1;
         // panel: row block i = wave: Z = A[i][kk] (old), Y = Z Pi'
         if (wave != kk) {
@@ -1091,8 +1105,10 @@ __global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int m
     if (threadIdx.x == 0) bad = 0;
     const double* tkk = c.src + ((size_t)k * c.nblk + k) * JTT;  // pivot tile (k, k) as the steps before k left it
     for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = tkk[i];
+    __shared__ double thr[JT];
+    if (c.G && threadIdx.x < JT) thr[threadIdx.x] = A.pol_tau * c.G[((size_t)k * c.nblk + k) * JTT + (size_t)threadIdx.x * (JT + 1)];
     __syncthreads();
-    inv64_lds(Am, &sc, &bad);
+    inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
     store_pivot_inverse(Am, c.Pk);
     // a non-positive pivot (the matrix is SPD in exact arithmetic) is counted, not fatal: the sweep needs no square roots, and with
     // Newton weights of 1e9 the last interior-point iterations work at the edge of double precision
@@ -1240,8 +1256,10 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         if (last) outT[i] = Am[cc * LDA + r];
     }
     if (look) {
+        __shared__ double thr[JT];
+        if (c.G && tid < JT) thr[tid] = A.pol_tau * c.G[((size_t)(k + 1) * nblk + (k + 1)) * JTT + (size_t)tid * (JT + 1)];
         __syncthreads();
-        inv64_lds(Am, &sc, &bad);
+        inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
         store_pivot_inverse(Am, c.Pn);
         if (bad && tid == 0) *c.bad += 1.0;
     }
@@ -1416,6 +1434,7 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
 __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const JDims& d, int kind, int s, int mid, int k, int chain) {
     SweepCtx c;
     c.bad = w.st + ST_BADPIV;
+    c.G = nullptr;
     if (kind == 0) {
         const Chain ch = chain_step(d, chain, s, mid != 0);
         c.active = ch.active && w.st[ST_STATE] == 0.0 && w.st[ST_RETRY] == 0.0 && w.st[ST_GO] == 0.0;
@@ -1434,6 +1453,7 @@ __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const
         c.dst = ((k + p0 + 1) & 1) ? p.W1 : p.W0;
         c.Pk = p.P + (size_t)(k & 1) * JTT, c.Pn = p.P + (size_t)((k + 1) & 1) * JTT;
         c.Y = p.Y;
+        c.G = p.G;
     }
     return c;
 }
@@ -1600,6 +1620,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // attempt costs more than an iteration and never succeeded on the 50 maps --, so ONE early attempt at 1e-8: 3.07 -> 2.64 s per sweep)
     A.early_mu[0] = 1e-8, A.early_mu[1] = 0.0;
     if (getenv("RBP_JQ_EARLY")) sscanf(getenv("RBP_JQ_EARLY"), "%lf,%lf", &A.early_mu[0], &A.early_mu[1]);  // experiments
+    A.pol_tau = getenv("RBP_JQ_POLTAU") ? atof(getenv("RBP_JQ_POLTAU")) : 2e-7;
     A.exit_mu = getenv("RBP_JQ_EXITMU") ? atof(getenv("RBP_JQ_EXITMU")) : 1e-9;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
