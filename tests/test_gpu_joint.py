@@ -180,7 +180,7 @@ def test_joint_64_whole_sweep_against_the_oracle(monkeypatch):
     (tests/golden/joint64_sweep.npz: objective of every map and the control points of agents 0, 21, 42, 63; the oracle needs 5.5 min per map,
     tests/golden/make_joint_sweep_golden.py).  Where the polish was accepted the GPU's control points are within CTRL_TOL of the oracle's
     certified optimum and the objectives agree to 1e-8; where it was refused the answer is the interior-point iterate with its reported
-    residual: feasible, objective within 1e-4 relative.  At least 40 of the 50 maps must be polished (44 when this was written)."""
+    residual: feasible, objective within 1e-4 relative.  At least 40 of the 50 maps must be polished (49 when this was written)."""
     path = os.path.join(GOLDEN, "joint64_sweep.npz")
     if not os.path.exists(path):
         pytest.skip("tests/golden/joint64_sweep.npz not generated (40 min of oracle time: tests/golden/make_joint_sweep_golden.py)")
