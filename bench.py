@@ -448,6 +448,20 @@ def main():
                                "flops_per_step": ct["qp_flops"], "ipm_iterations_per_step": ct["qp_ipm_iters"],
                                "qps_per_step": ct["qp_solves"], "qps_polished_per_step": ct["qp_polished"], "kkt_max": ct["kkt_max"]}
             out["config"]["qp_kernel_variant"] = "grid-wide joint (jqp)"
+            # the dominant kernel's own rate, from the committed rocprofv3 summary of this very command (a constant tied to the joint
+            # solver's sources by hash, like traffic_profiled above; tools/collect_joint_profiles.sh + profiles/README.md say how)
+            try:
+                jk = json.load(open(os.path.join(ROOT, "profiles", "r04_joint_kernel.json")))
+                base = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
+                h = hashlib.sha256()
+                for f in sorted(os.listdir(base)):
+                    if f.startswith("jqp"):
+                        h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
+                if jk["joint_source_sha"] == h.hexdigest()[:16] and jk["missions_per_gpu"] == K and jk["agents"] == N:
+                    out["roofline"]["kernel_profiled"] = {"kernel": jk["kernel"], "achieved": jk["tflops"], "unit": "TFLOP/s",
+                                                          "frac": jk["frac_of_fp64_mfma_peak"], "source": "profiles/r04_joint_kernel.json"}
+            except Exception:
+                pass
         # the single-mission latency and the CPU baseline are rank-0, N = 1 legs (the other ranks would only wait for them)
         if world_size == 1 and N == 64 and args.batch_size == 4 and args.iteration == 1 and not args.joint and not args.no_latency:
             try:
