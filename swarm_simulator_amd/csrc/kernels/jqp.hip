@@ -24,6 +24,13 @@
 //     assembly of T_{j+1} from the sweeps' accumulators (T_j is never stored).  The elimination is TWISTED (both ends towards the
 //     middle knot): half the dependent depth, the two chains share every launch;
 //   * SUBSTITUTIONS are matrix-vector products with the stored inverses (16-row slabs, one launch per knot step and direction).
+//   * two SCHEDULES of that sweep: look-ahead as described (few missions: the dependent chain is what counts) and bulk (eight or more
+//     resident missions: jq_update_bulk without LDS at three workgroups per CU, the pivot inverse in a launch of its own);
+//   * on top of Mehrotra's direction ONE centrality corrector per iteration (Gondzio) on the factorisation already paid for, and a
+//     SAFEGUARD that takes back a step which loses the dual residual after an acceptable iterate (explicit inverses at Newton weights
+//     of 1e9: see jq_ctrl(1));
+//   * the active-set POLISH (jqp_polish.inc) reuses the tile sweep for S_AA^-1, rank-revealing there (dependent active rows are deleted
+//     from a dual solve instead of eliminated).
 //
 // Layout: knot matrices are TILE-MAJOR (64 x 64 tiles of 32 KB, row-major inside), order nkp = nk rounded up to 64 (identity
 // padding).  During the sweep only tiles I >= J are valid; the last step writes S_j^-1 with both triangles.
