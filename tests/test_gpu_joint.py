@@ -155,6 +155,21 @@ def test_joint_256_agents_solved_and_feasible(monkeypatch):
             assert rep["stationarity"] < 1e-5 and rep["complementarity"] < 1e-8, tag
 
 
+def test_joint_schedules_of_the_tile_sweep_agree(monkeypatch):
+    """look-ahead (default for fewer than eight resident missions) and bulk schedule (jq_update_bulk + a pivot launch per step) of the tile
+    sweep on the same mission: the same optimum (both polished, control points within CTRL_TOL; the update kernels accumulate in the same
+    order, so in practice the same bits)"""
+    p, m, w, init = _inputs(64, 7)
+    monkeypatch.setenv("RBP_JQ_SCHED", "look")
+    look = _plan(p, m, w, init, True, monkeypatch)
+    monkeypatch.setenv("RBP_JQ_SCHED", "bulk")
+    bulk = _plan(p, m, w, init, True, monkeypatch)
+    assert look.qp_unpolished == 0 and bulk.qp_unpolished == 0
+    assert look.qp_iterations == bulk.qp_iterations
+    assert np.abs(look.ctrl - bulk.ctrl).max() < CTRL_TOL
+    assert abs(look.total_cost - bulk.total_cost) <= 1e-10 * max(1.0, look.total_cost)
+
+
 def test_joint_64_session_of_six_maps_is_polished(monkeypatch):
     """six 64-agent joint missions in one session (maps 1..6): every one ends as the KKT-certified optimum of the active-set polish.  Before
     the polish knew about TWINS (the same reduced constraint written twice: last control point of a segment = first of the next under a
