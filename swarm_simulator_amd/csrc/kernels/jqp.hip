@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void jq_sweep(JArgs A) {
     if (w.st[ST_STATE] != 0.0) return;
     if (PASS == PASS_CAND || PASS == PASS_VERIFY) {
         if (w.st[ST_GO] == 0.0 || w.st[ST_PSTATE] != (double)(PASS == PASS_CAND ? PS_SOLVE : PS_PRIMAL)) return;
-    } else if (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0)
-        return;
+    } else if (w.st[ST_GO] != 0.0 || (PASS != PASS_UPBUILD && w.st[ST_RETRY] != 0.0))
+        return;  // (a mission whose polish request is waiting for company is frozen: see launch_planner_joint)
     if (PASS == PASS_UPBUILD && A.retry_only && w.st[ST_RETRY] == 0.0) return;  // (a repeat launch: only for missions whose step was refused)
     constexpr bool kmulr = (PASS == PASS_KMUL_A || PASS == PASS_KMUL_D || PASS == PASS_KMUL_G);
     constexpr bool gond = (PASS == PASS_GOND);
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void jq_post(JArgs A) {
     const int mission = blockIdx.y, tid = threadIdx.x;
     const Ws w = carve(A, mission);
     __shared__ double red[8];
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     if (CORR == 2 && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void jq_apply_F(JArgs A, int which) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     if (A.gond_only && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission];
     const JDims d = jdims(N, M);
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void jq_stepx(JArgs A) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || (A.retry_only && w.st[ST_RETRY] == 0.0)) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_GO] != 0.0 || (A.retry_only && w.st[ST_RETRY] == 0.0)) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const int nx = N * 3 * 6 * M, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nx) return;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void jq_gcopy(JArgs A) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GOK] == 0.0) return;  // (ST_GOK lasts until the next iteration's step sweep)
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0 || w.st[ST_GOK] == 0.0) return;  // (ST_GOK lasts until the next iteration's step sweep)
     const int nx = S.N * 3 * 6 * S.Mk[mission], i = blockIdx.x * 256 + threadIdx.x;
     if (i < nx) w.dx[i] = w.dx2[i];
 }
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void jq_refine(JArgs A, int op, int which) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     if (w.st[ST_NREF] <= (double)(op == 0 ? 0 : A.ref_step)) return;
     if (A.gond_only && w.st[ST_GACT] == 0.0) return;
     const int N = S.N, M = S.Mk[mission];
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
     const Ws w = carve(A, mission);
     __shared__ double red[8];
     double* st = w.st;
-    if (st[ST_STATE] != 0.0) return;
+    if (st[ST_STATE] != 0.0 || (which >= 1 && st[ST_GO] != 0.0)) return;  // (which >= 1: a mission waiting for its polish is frozen)
     const JDims d = jdims(S.N, S.Mk[mission]);
     const int nsw = S.N * d.nch, npost = (d.nj * 3 * S.N + 255) / 256;
     const double nrows = st[ST_NROWS];
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void jq_prep(JArgs A, int s, int mid) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
     const JDims d = jdims(N, M);
     const Chain c = chain_step(d, chain, s, mid != 0);
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
     const DevSession& S = A.S;
     const int mission = blockIdx.z, chain = blockIdx.y, tid = threadIdx.x;
     const Ws w = carve(A, mission);
-    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
     const Chain c = chain_step(d, chain, s, mode == 1 || mode == 3);
     if (!c.active || (int)blockIdx.x * 16 >= d.nkp) return;
@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(256) void jq_finish(JArgs A) {
 __global__ void jq_count(JArgs A) {
     const int mission = blockIdx.x;
     const Ws w = carve(A, mission);
-    if (threadIdx.x != 0 || w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0) return;
+    if (threadIdx.x != 0 || w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const JDims d = jdims(A.S.N, A.S.Mk[mission]);
     const double nb = d.nblk, per_knot = nb * ((nb - 1) * nb / 2 + (nb - 1)) * 2.0 * JT * JT * JT;
     w.st[ST_FLOPS] += d.nj * per_knot + 2.0 * (2.0 * d.nj - 1.0) * 2.0 * (double)d.nkp * d.nkp;
@@ -1728,7 +1728,8 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jp_end, dim3(K), 0, A);
         return RBP_OK;
     };
-    int iters = 0, rc = RBP_OK;
+    int iters = 0, rc = RBP_OK, go_waited = 0;
+    const int pol_wait = getenv("RBP_JQ_POLWAIT") ? atoi(getenv("RBP_JQ_POLWAIT")) : 8;
     const int max_rounds = JQ_MAX_ITERS + 48;
     for (int it = 0; it < max_rounds; ++it) {
         if (it == 0) JQ_LAUNCH(jq_sweep<PASS_BUILD>, dim3(nsw, K), 0, A);
@@ -1755,9 +1756,21 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         nref_round = 0;
         for (int k = 0; k < K; ++k)
             if (state_h[(size_t)k * ST_N + ST_STATE] == 0.0) nref_round = std::max(nref_round, (int)state_h[(size_t)k * ST_N + ST_NREF]);
-        bool any_go = false;
-        for (int k = 0; k < K; ++k) any_go = any_go || (state_h[(size_t)k * ST_N + ST_STATE] == 0.0 && state_h[(size_t)k * ST_N + ST_GO] != 0.0);
+        bool any_go = false, any_ipm = false;
+        for (int k = 0; k < K; ++k) {
+            const bool run_k = state_h[(size_t)k * ST_N + ST_STATE] == 0.0, go_k = state_h[(size_t)k * ST_N + ST_GO] != 0.0;
+            any_go = any_go || (run_k && go_k), any_ipm = any_ipm || (run_k && !go_k);
+        }
+        // A polish call costs as many exchange rounds as its SLOWEST mission needs, whoever else takes part, and with many missions the
+        // requests trickle in over a dozen interior-point rounds: requests wait up to pol_wait rounds for company while other missions still
+        // iterate (a waiting mission is frozen -- every interior-point kernel skips missions with ST_GO set -- and loses nothing: the round
+        // runs anyway); a session whose missions are all waiting, or a lone mission, is served at once.
+        if (any_go && any_ipm && go_waited < pol_wait) {
+            go_waited++;
+            any_go = false;
+        }
         if (any_go) {
+            go_waited = 0;
             if ((rc = polish()) != RBP_OK) break;
             // (missions the polish has finished are skipped by the kernels below; if none is left the next poll ends the loop)
         }
