@@ -82,6 +82,12 @@ struct rbp_session {
     bool planner_ok = true;   // false: the batch is wider than the QP kernel supports (corridor-only session)
     bool joint_wide = false;  // the joint QP (plan/sequential = false) runs on the grid-wide solver (kernels/jqp.hip)
     JointStats joint_stats{};
+    // phase-split schedule of the batch QPs (kernels/qp_phase.inc): the session's missions run as up to QP_MAX_GROUPS groups on streams
+    // of their own, forked from / joined into the caller's stream by events (created on first use)
+    static constexpr int QP_MAX_GROUPS = 8;
+    hipStream_t gstream[QP_MAX_GROUPS] = {};
+    hipEvent_t gevent[QP_MAX_GROUPS + 1] = {};
+    int n_gstream = 0;
     int last_stages = 0;      // stages of the last rbp_session_run (time_scale only concerns a run that included the planner)
 };
 
@@ -405,6 +411,14 @@ int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t age
     return RBP_OK;
 }
 
+// which schedule runs the batch QPs: the phase-split one (kernels/qp_phase.inc: chip-wide row sweeps, one workgroup per mission for the
+// chains) or one workgroup per mission for everything (qp_batch_kernel)
+static bool qp_phase_split(const rbp_session* s) {
+    const char* e = getenv("RBP_QP_PATH");  // developer override (A/B runs): "phase" | "mono"
+    if (e) return e[0] == 'p';
+    return false;
+}
+
 int rbp_session_run(rbp_session* s, int stages, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     hipStream_t st = (hipStream_t)stream;
@@ -424,6 +438,19 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
         if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats);
         if (rc) return fail(rc, "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
+    } else if ((stages & RBP_STAGE_PLANNER) && qp_phase_split(s)) {
+        const char* ge = getenv("RBP_QP_GROUPS");  // developer override (A/B runs)
+        int G = ge ? atoi(ge) : (s->d.K >= 1024 ? 4 : (s->d.K >= 256 ? 2 : 1));
+        G = std::max(1, std::min(G, std::min((int)rbp_session::QP_MAX_GROUPS, s->d.K)));
+        while (s->n_gstream < G) {
+            const int g = s->n_gstream;
+            if (g == 0) HIP_TRY(hipEventCreateWithFlags(&s->gevent[0], hipEventDisableTiming));
+            HIP_TRY(hipStreamCreateWithFlags(&s->gstream[g], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&s->gevent[1 + g], hipEventDisableTiming));
+            s->n_gstream++;
+        }
+        const char* re = getenv("RBP_QP_ROUNDS");  // developer override: round budget
+        launch_planner_phased(s->d, s->qp_ws, s->qp_ws_per_mission, st, s->gstream, s->gevent, G, re ? atoi(re) : 0);
     } else if (stages & RBP_STAGE_PLANNER) {
         // two workgroups per CU (the 128-VGPR build) pay off as soon as there are more missions than CUs: the 256-VGPR build
         // would need a second round (measured at 300/400/500 missions: +17-21 %)
@@ -570,6 +597,11 @@ int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream) {
 
 void rbp_session_destroy(rbp_session* s) {
     if (!s) return;
+    if (s->n_gstream > 0) {
+        (void)hipSetDevice(s->device);
+        (void)hipEventDestroy(s->gevent[0]);
+        for (int g = 0; g < s->n_gstream; ++g) (void)hipStreamDestroy(s->gstream[g]), (void)hipEventDestroy(s->gevent[1 + g]);
+    }
     if (s->ctx) {
         s->ctx->busy = false;  // the arena stays with the context
     } else if (s->arena.base) {

@@ -202,7 +202,16 @@ __host__ __device__ inline size_t ws_int_count(int N, int M, int nbmax) {
            3 * (size_t)nbmax * M * N /*nrm (floats)*/ + 8;
 }
 
-__host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) {
+// PHASE-SPLIT PATH (round 5, see ph_advance): per mission a state record and the partial reductions of the chip-wide row sweeps live behind
+// the workspace proper (offset ws_core_doubles rounded up to four doubles)
+#define PH_STATE_DOUBLES 32  // >= sizeof(PhState) / 8
+__host__ __device__ inline int ph_nwg(int nb, int M) { return (nb * 6 * M + 255) / 256; }  // workgroups of a chip-wide sweep over one batch QP
+__host__ __device__ inline size_t ph_extra_doubles(int M, int nbmax) { return PH_STATE_DOUBLES + 8 * (size_t)ph_nwg(nbmax, M) + 8; }
+__host__ __device__ inline size_t ws_core_doubles(int N, int M, int nbmax);
+__host__ __device__ inline size_t ph_state_offset(int N, int M, int nbmax) { return (ws_core_doubles(N, M, nbmax) + 3) & ~size_t(3); }
+__host__ __device__ inline size_t ws_doubles(int N, int M, int nbmax) { return ph_state_offset(N, M, nbmax) + ph_extra_doubles(M, nbmax); }
+
+__host__ __device__ inline size_t ws_core_doubles(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
     size_t n = 7 * d.nslot_max + 12 * (size_t)nbmax * d.oq + (size_t)(d.npb ? d.npb : 1) * d.oq + 3 * (size_t)nbmax * 3 * d.oq +
                2 * (size_t)d.nj * d.nk + (size_t)d.nj * d.ldb * d.ldb + 2 * (size_t)d.nj * (d.nk < 36 ? d.nk : 36) * (d.nk < 36 ? d.nk : 36) +
@@ -504,8 +513,10 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
 //   frozen  (a,f,j6):       sg * n . x_a <= -rr + sg * n . dummy_f        :645-666   sg = +1 if a < f else -1
 // Control points j6 < 3 and j6 >= 6M-3 are pinned by the end-state equalities: their rows are constants and are only checked
 // once (presolve).  Work item = one free control point of one batch agent with ALL its rows (see the note above QpWs).
+// wi0 / wi_end / stride: the control points this thread takes (default: the whole batch QP on one workgroup; the chip-wide sweeps of the
+// phase-split path hand every workgroup a range of tiles, see ph_sweep)
 template <int PASS>
-__device__ void row_pass(const RowCtx& c, PassIO& io) {
+__device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int wi_end = 1 << 30, int stride = QP_THREADS) {
     const QpDims& d = c.d;
     const QpWs& w = c.w;
     const int oq = d.oq, N = d.N, M = d.M, nb = d.nb;
@@ -517,7 +528,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io) {
     constexpr bool need_da = (PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
     constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_VERIFY || PASS == PASS_UPBUILD);
     const int ncp = nb * oq;
-    for (int wi = threadIdx.x; wi < ncp; wi += QP_THREADS) {
+    const int wi_stop = wi_end < ncp ? wi_end : ncp;
+    for (int wi = wi0; wi < wi_stop; wi += stride) {
         const int grp = w.fperm[wi / 6], a = grp / M, seg = grp - a * M, i = wi % 6, j6 = 6 * seg + i, it = a * oq + j6;
         const bool pinned = (j6 < 3 || j6 >= oq - 3);
         if (pinned != pinned_only) continue;
@@ -2147,47 +2159,15 @@ __device__ double trc_sum(const double* p, size_t n, double* red) {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
-// one batch QP of one mission (all threads of the workgroup)
+// set-up of one batch QP (all threads of the workgroup): mission constants, the SFC box of every (batch agent, segment), the pinned end
+// control points, the presolve lists and the row constants.  false: the mission was abandoned (S.status set).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
-                                              int reset_cost, int lds_doubles, int pass_index) {
-    const int tid = threadIdx.x;
-    if (S.status[mission] != 0) return;
-    // M of this mission: made wave-uniform explicitly (an SGPR like every other dimension; as a per-lane value it was spilled
-    // and reloaded under divergent control flow with some lanes reading garbage)
-    const int N = S.N, M = __builtin_amdgcn_readfirstlane(S.Mk[mission]), MS = S.M;  // MS: slot stride of the per-mission arrays
-    const int first = batch * nbmax;
-    const int nb = min(nbmax, N - first);
-    if (nb <= 0) return;
-    RowCtx c;
-    c.scal = S.scalars + (size_t)mission * SC_N, c.mission = mission, c.lds_avail = lds_doubles - 32;
-    c.d = make_dims(N, M, first, nb);
-    c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
-    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
-    c.ctrl = ctrl;
-    c.normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
-    c.radius = S.radius + (size_t)mission * N;
+__device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, double* ctrl, const double* T, int mission, int first, int nb,
+                                               int* flag, double* lds, int& frozen_free_rows) {
+    const int tid = threadIdx.x, N = S.N;
     const QpDims& d = c.d;
     const QpWs& w = c.w;
-    const double* T = S.T + (size_t)mission * (MS + 1);
-    double* scal = S.scalars + (size_t)mission * SC_N;
-
-    // dynamic LDS: [0,32) reduction scratch + flags (always live), then a work area shared in turn by the block
-    // factorisation (3 blocks), the staged substitutions (4 padded blocks + rhs) and the polish
-    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
-    double* red = lds_raw;  // 16
-    int* flag = (int*)(lds_raw + 16);
-    double* lds = lds_raw + 32;
-    double* lA = lds;
-#ifdef QP_PROFILE
-    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, scal};
-#else
-    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, nullptr};
-#endif
-    double* red2 = red;
-    int* flag2 = flag;
-
-    PROF_DECL;
+    const int M = d.M;
     mission_constants(d, T, const_cast<QpWs&>(w));
     init_block_pads(d, w);
 
@@ -2245,7 +2225,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     __threadfence();
     __syncthreads();
-    if (__hip_atomic_load(&S.status[mission], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // set above: an agent without boxes
+    if (__hip_atomic_load(&S.status[mission], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;  // set above: an agent without boxes
 
     // ---- presolve: a frozen-neighbour row  sg*n.(d_f - x_a) >= r_a + r_f  is implied by the SFC bounds of (a, segment) when
     // its slack is positive for EVERY x_a in the box; such rows cannot be active and are dropped (exact: the feasible
@@ -2315,7 +2295,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     __threadfence_block();
     __syncthreads();
-    const int frozen_free_rows = *flag;
+    frozen_free_rows = *flag;
     __syncthreads();
     // sweep work order: the threads of a wavefront walk the row lists of their control points in lockstep, so a wave
     // costs as much as its longest list.  Handing out the (agent, segment) groups by falling row count puts lists of
@@ -2383,6 +2363,53 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     }
     __threadfence_block();
     __syncthreads();
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// one batch QP of one mission (all threads of the workgroup)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
+                                              int reset_cost, int lds_doubles, int pass_index) {
+    const int tid = threadIdx.x;
+    if (S.status[mission] != 0) return;
+    // M of this mission: made wave-uniform explicitly (an SGPR like every other dimension; as a per-lane value it was spilled
+    // and reloaded under divergent control flow with some lanes reading garbage)
+    const int N = S.N, M = __builtin_amdgcn_readfirstlane(S.Mk[mission]), MS = S.M;  // MS: slot stride of the per-mission arrays
+    const int first = batch * nbmax;
+    const int nb = min(nbmax, N - first);
+    if (nb <= 0) return;
+    RowCtx c;
+    c.scal = S.scalars + (size_t)mission * SC_N, c.mission = mission, c.lds_avail = lds_doubles - 32;
+    c.d = make_dims(N, M, first, nb);
+    c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
+    double* ctrl = S.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    c.ctrl = ctrl;
+    c.normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
+    c.radius = S.radius + (size_t)mission * N;
+    const QpDims& d = c.d;
+    const QpWs& w = c.w;
+    const double* T = S.T + (size_t)mission * (MS + 1);
+    double* scal = S.scalars + (size_t)mission * SC_N;
+
+    // dynamic LDS: [0,32) reduction scratch + flags (always live), then a work area shared in turn by the block
+    // factorisation (3 blocks), the staged substitutions (4 padded blocks + rhs) and the polish
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    double* red = lds_raw;  // 16
+    int* flag = (int*)(lds_raw + 16);
+    double* lds = lds_raw + 32;
+    double* lA = lds;
+#ifdef QP_PROFILE
+    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, scal};
+#else
+    const BlkArgs ba{d.nk, d.nj, d.ldb, c.lds_avail, w.Td, w.To, w.Lf, w.Ek, nullptr};
+#endif
+    double* red2 = red;
+    int* flag2 = flag;
+
+    PROF_DECL;
+    int frozen_free_rows = 0;
+    if (!qp_setup_batch(S, c, ctrl, T, mission, first, nb, flag, lds, frozen_free_rows)) return;
     PROF(8);  // batch setup: constants, SFC boxes, presolve lists, row constants
     PassIO io;
     __shared__ RowCtx c_lds;  // the sweeps' view of the row context (see sweep<>)
@@ -2705,6 +2732,10 @@ __global__ __launch_bounds__(256) void qp_order_kernel(DevSession S) {
         S.qp_order[k] = k;
 }
 
+#if QP_THREADS == 256
+#include "qp_phase.inc"
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
 // epilogue: Bernstein -> monomial (rbp_planner.hpp:170-196), timeScale (:209-266)
 // ------------------------------------------------------------------------------------------------------------
@@ -2897,6 +2928,23 @@ void launch_planner_epilogue(const DevSession& s, hipStream_t st) {
 }
 #endif
 
+// dynamic LDS of the QP kernels: the largest of the tiled path's vectors, the polish (dual factor + 3x3 chain factor) and the wave
+// path's staged substitutions (a short last batch may take the wave path even when bs > 4)
+static size_t qp_lds_bytes(int bs, int M) {
+    const int nk = 9 * bs;
+    const int nkw = std::min(nk, 36);
+    size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
+    lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
+    lds = std::max(lds, sizeof(double) * (16 + (size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KS_VLEN + 2 * 64 + 64));  // solve_staged
+    // chain areas + assembly progress counters (+ the assembling waves' LDS scratch in the 512-thread build)
+    lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + ASM_HELPERS * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
+    if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
+        const size_t lb = (size_t)((nk + 15) & ~15);
+        lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
+    }
+    return lds;
+}
+
 void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st) {
     const int N = s.N, M = s.M;
     // setBatch (rbp_planner.hpp:849-872)
@@ -2916,19 +2964,7 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
             (void)rbp_set_error(RBP_ERR_BAD_ARGUMENT, "launch_planner: batch wider than the QP kernel supports");
             return;
         }
-        const int nk = 9 * bs;
-        // dynamic LDS: the largest of the tiled path's vectors, the polish (dual factor + 3x3 chain factor) and the
-        // wave path's staged substitutions (a short last batch may take the wave path even when bs > 4)
-        const int nkw = std::min(nk, 36);
-        size_t lds = sizeof(double) * (2 * (size_t)((nk + 15) & ~15) + QP_THREADS + 32) + 16;
-        lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
-        lds = std::max(lds, sizeof(double) * (16 + (size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KS_VLEN + 2 * 64 + 64));  // solve_staged
-        // chain areas + assembly progress counters (+ the assembling waves' LDS scratch in the 512-thread build)
-        lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + ASM_HELPERS * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
-        if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
-            const size_t lb = (size_t)((nk + 15) & ~15);
-            lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);
-        }
+        const size_t lds = qp_lds_bytes(bs, M);
         (void)hipFuncSetAttribute((const void*)qp_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (s.p.iteration > 0 && s.qp_order) hipLaunchKernelGGL(qp_order_kernel, dim3((s.K + 255) / 256), dim3(256), 0, st, s);
         if (s.p.iteration > 0)
@@ -2942,3 +2978,70 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
     hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
     hipLaunchKernelGGL(timescale_kernel, dim3(s.K), dim3(256), 0, st, s);
 }
+
+#if QP_THREADS == 256
+// The PHASE-SPLIT schedule (kernels/qp_phase.inc): a fixed budget of rounds is enqueued on G streams (one group of missions each, forked
+// from and joined back into the caller's stream by events), nothing is synchronised.  rounds <= 0: the default budget of
+// QP_ROUNDS_PER_QP rounds per batch QP of the schedule (a batch QP takes ~18 interior-point iterations = rounds).
+#ifndef QP_ROUNDS_PER_QP
+#define QP_ROUNDS_PER_QP 48
+#endif
+void launch_planner_phased(const DevSession& s, void* qp_ws, size_t ws_bytes_per_mission, hipStream_t st, hipStream_t* gs, hipEvent_t* gev, int G,
+                           int rounds) {
+    const int N = s.N, M = s.M, K = s.K;
+    int bs = s.p.sequential ? s.p.batch_size : N;  // setBatch (rbp_planner.hpp:849-872)
+    if (bs <= 0) bs = 1;
+    if (bs > N) bs = N;
+    const int bmax = (N + bs - 1) / bs;
+    int biter = s.p.sequential ? s.p.batch_iter : 1;
+    if (s.p.sequential && (biter < 0 || biter > bmax)) biter = bmax;
+    const size_t total = (size_t)K * N * 3 * 6 * M;
+    hipLaunchKernelGGL(dummy_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, s);
+    if (biter > 0 && s.p.iteration > 0) {
+        if (bs > QP_MAX_NB) {
+            (void)rbp_set_error(RBP_ERR_BAD_ARGUMENT, "launch_planner: batch wider than the QP kernel supports");
+            return;
+        }
+        const size_t lds = qp_lds_bytes(bs, M);
+        const int lds_doubles = (int)(lds / sizeof(double)) - 2;
+        (void)hipFuncSetAttribute((const void*)ph_advance, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)ph_corr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        double* ws = (double*)qp_ws;
+        const size_t stride = ws_bytes_per_mission / sizeof(double), st_off = ph_state_offset(N, M, bs);
+        if (rounds <= 0) rounds = s.p.iteration * biter * QP_ROUNDS_PER_QP + 8;
+        hipLaunchKernelGGL(ph_init, dim3((K + 255) / 256), dim3(256), 0, st, s, ws, stride, st_off);
+        if (G < 1) G = 1;
+        if (G > K) G = K;
+        const bool fork = G > 1 || gs[0] != st;
+        if (fork) {
+            (void)hipEventRecord(gev[0], st);
+            for (int g = 0; g < G; ++g) (void)hipStreamWaitEvent(gs[g], gev[0], 0);
+        }
+        const int nwg = ph_nwg(bs, M);
+        for (int r = 0; r < rounds; ++r)
+            for (int g = 0; g < G; ++g) {
+                const int m0 = (int)((long long)K * g / G), kg = (int)((long long)K * (g + 1) / G) - m0;
+                hipStream_t q = gs[g];
+                hipLaunchKernelGGL(ph_advance, dim3(kg), dim3(QP_THREADS), lds, q, s, ws, stride, st_off, m0, s.p.iteration, biter, bs, lds_doubles);
+                hipLaunchKernelGGL(ph_sweep<PASS_AFF>, dim3(nwg, kg), dim3(256), 0, q, s, ws, stride, st_off, m0, bs);
+                hipLaunchKernelGGL(ph_corr, dim3(kg), dim3(QP_THREADS), lds, q, s, ws, stride, st_off, m0, bs, lds_doubles);
+                hipLaunchKernelGGL(ph_sweep<PASS_STEP>, dim3(nwg, kg), dim3(256), 0, q, s, ws, stride, st_off, m0, bs);
+                hipLaunchKernelGGL(ph_ctrl, dim3(kg), dim3(QP_THREADS), 0, q, s, ws, stride, st_off, m0, bs, 0);
+                hipLaunchKernelGGL(ph_sweep<PASS_UPBUILD>, dim3(nwg, kg), dim3(256), 0, q, s, ws, stride, st_off, m0, bs);
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipLaunchKernelGGL(ph_ctrl, dim3(kg), dim3(QP_THREADS), 0, q, s, ws, stride, st_off, m0, bs, 1);
+                    hipLaunchKernelGGL(ph_sweep<PASS_UPBUILD>, dim3(nwg, kg), dim3(256), 0, q, s, ws, stride, st_off, m0, bs);
+                }
+            }
+        if (fork)
+            for (int g = 0; g < G; ++g) {
+                (void)hipEventRecord(gev[1 + g], gs[g]);
+                (void)hipStreamWaitEvent(st, gev[1 + g], 0);
+            }
+        hipLaunchKernelGGL(ph_finish, dim3((K + 255) / 256), dim3(256), 0, st, s, ws, stride, st_off);
+    }
+    const size_t tot2 = (size_t)K * N * 3 * M;
+    hipLaunchKernelGGL(coef_kernel, dim3((unsigned)std::min<size_t>((tot2 + 255) / 256, 4096)), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(timescale_kernel, dim3(K), dim3(256), 0, st, s);
+}
+#endif

@@ -90,5 +90,8 @@ void launch_corridor(const DevSession& s, hipStream_t st);
 // kernels/qp.hip is built twice: _w2 = 256 VGPRs, one workgroup per CU; _w4 = 128 VGPRs, two workgroups per CU
 void launch_planner_w2(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
 void launch_planner_w4(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
+// the phase-split schedule of the batch QPs (kernels/qp_phase.inc; exported by the 256-thread build): gs[G] group streams, gev[1 + G] events
+void launch_planner_phased(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st, hipStream_t* gs, hipEvent_t* gev, int G,
+                           int rounds);
 size_t planner_workspace_bytes_w2(int N, int M, int batch_size_eff);
 size_t planner_workspace_bytes_w4(int N, int M, int batch_size_eff);
