@@ -146,19 +146,45 @@ int rbp_planner_update(const rbp_mission* mission, const rbp_param* param, rbp_p
  * swarm_traj_planner_rbp_test_all.cpp:49-103).  `run` only enqueues kernels on `stream`
  * (a hipStream_t passed as void*; NULL = default stream) and never synchronises -- with ONE exception: the PLANNER stage of a
  * non-sequential plan (plan/sequential = false, the reference's code default param.hpp:67: one joint QP over all agents,
- * rbp_planner.hpp:857-859) with 16 agents or more runs on the grid-wide solver (kernels/jqp.hip: a launch per phase of the
- * interior-point method over all CUs), whose host loop learns once per iteration whether any mission is still running: that
- * `run` SYNCHRONISES `stream` before it returns.  RBP_JOINT_WIDE=0 / 1 forces the one-workgroup kernel (<= 64 agents, no
- * synchronisation) / the grid-wide solver. */
+ * rbp_planner.hpp:857-859) with rbp_solver_opts.joint_wide_min_agents (16) agents or more runs on the grid-wide solver
+ * (kernels/jqp.hip: a launch per phase of the interior-point method over all CUs), whose host loop learns once per iteration whether
+ * any mission is still running: that `run` SYNCHRONISES `stream` before it returns. */
 typedef struct rbp_session rbp_session;
 
 enum { RBP_STAGE_CORRIDOR = 1, RBP_STAGE_PLANNER = 2, RBP_STAGE_ALL = 3 };
+
+/* ---- solver options (ABI 4) --------------------------------------------------------------------
+ * What a caller may legitimately choose about HOW the QPs are solved (never WHAT is computed: every setting ends in the same
+ * KKT-verified optimum or the same error).  The library reads NO environment variables: these options are the only switches.
+ * Fill the struct with rbp_solver_opts_defaults, change fields, hand it to a session (before its first `run`) or to a context
+ * (sessions and one-shot calls made in it inherit the options; ctx == NULL: the calling thread's default context). */
+typedef struct rbp_solver_opts {
+    int32_t size;                  /* sizeof(rbp_solver_opts) of the caller's header (set by rbp_solver_opts_defaults; checked) */
+    int32_t polish;                /* 1: every QP ends with the active-set polish (the certified optimum); 0: the interior-point answer
+                                      with its reported KKT residual (diagnostics) */
+    int32_t joint_wide_min_agents; /* 16: a joint QP (plan/sequential = false) of at least this many agents runs on the grid-wide
+                                      solver (kernels/jqp.hip, no limit on N, `run` synchronises); fewer agents -- or 0 = never --
+                                      run on one workgroup per mission (<= 64 agents, `run` only enqueues) */
+    int32_t joint_corrector;       /* 1: one centrality corrector per interior-point iteration of the grid-wide solver */
+    int32_t joint_schedule;        /* 0: automatic; 1: look-ahead tile sweep (few missions); 2: bulk tile sweep (many missions) */
+    int32_t qp_schedule;           /* batch QPs of the sequential schedule: 0 automatic; 1: one workgroup per mission runs everything
+                                      (qp_batch_kernel); 2: phase split -- chip-wide row sweeps as kernels of their own
+                                      (kernels/qp_phase.inc) */
+    int32_t qp_variant;            /* qp_schedule 1: 0 automatic; 2: 512 threads, one workgroup per CU; 4: 256 threads, two per CU */
+    int32_t qp_block_order;        /* qp_schedule 1: 1 = a session that is run again starts its longest missions first; 0 = plain order */
+    int32_t qp_groups;             /* qp_schedule 2: streams the missions are spread over (0 automatic, at most 8) */
+    int32_t qp_rounds;             /* qp_schedule 2: round budget (0 automatic: 48 per batch QP of the schedule) */
+} rbp_solver_opts;
+void rbp_solver_opts_defaults(rbp_solver_opts* o);
 
 /* worlds/missions/plans: arrays of K structs (host side).  All plans share N; every mission keeps its own M (= ECBS makespan
  * + 2, ecbs_planner.hpp:41-43) and max_boxes, exactly as the reference's map sweep plans each map with its own M. */
 int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
                        const rbp_param* param, const rbp_plan* plans);
 int rbp_session_run(rbp_session* s, int stages, void* stream);
+/* solver options of this session (default: the context's, else rbp_solver_opts_defaults).  The QP workspace is reserved by the first
+ * PLANNER run, for the options then in force: a session that only runs the CORRIDOR stage reserves none. */
+int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o);
 /* restrict the CORRIDOR stage of later `run` calls to agents / pair rows [agent_begin, agent_end) (see
  * rbp_corridor_update_range); [0, N) restores the whole mission */
 int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t agent_end);
@@ -215,6 +241,9 @@ int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
  * current device.  device < 0 = the calling thread's current device.  One live session per context at a time. */
 typedef struct rbp_ctx rbp_ctx;
 int rbp_ctx_create(rbp_ctx** out, int device);
+/* options of every later session / one-shot call in this context; ctx == NULL: the calling thread's default context (created on the
+ * calling thread's current device if it does not exist yet) */
+int rbp_ctx_set_solver_opts(rbp_ctx* ctx, const rbp_solver_opts* o);
 void rbp_ctx_destroy(rbp_ctx* ctx);
 int rbp_ctx_corridor_update(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
 int rbp_ctx_planner_update(rbp_ctx* ctx, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan);
@@ -232,8 +261,10 @@ void rbp_release_thread_context(void);
 /* library/version/diagnostics.  RBP_ABI_VERSION changes whenever a struct of this header changes its layout; a binding built
  * against another header must refuse to run (rbp_plan / rbp_counters are written by the library).  rbp_sizeof lets a binding
  * that cannot see this header (ctypes, cgo) compare its own struct sizes with the library's. */
-#define RBP_ABI_VERSION 3  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: this header */
-enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4, RBP_SIZEOF_DEVICE_ARRAYS = 5 };
+#define RBP_ABI_VERSION 4  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: contexts, device views;
+                              4: rbp_solver_opts (the library no longer reads environment variables) */
+enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4, RBP_SIZEOF_DEVICE_ARRAYS = 5,
+       RBP_SIZEOF_SOLVER_OPTS = 6 };
 int rbp_abi_version(void);
 size_t rbp_sizeof(int which);
 const char* rbp_version(void);

@@ -28,7 +28,7 @@ RBP_ERR_BAD_ARGUMENT = 20
 RBP_ERR_NO_DEVICE = 30
 RBP_ERR_HIP = 31
 
-RBP_ABI_VERSION = 3  # include/rbp.h
+RBP_ABI_VERSION = 4  # include/rbp.h
 
 RBP_STAGE_CORRIDOR = 1
 RBP_STAGE_PLANNER = 2
@@ -74,6 +74,12 @@ class rbp_device_arrays(C.Structure):
     _fields_ = [("sfc_count", C.c_void_p), ("sfc_box", C.c_void_p), ("sfc_time", C.c_void_p), ("rsfc_normal", C.c_void_p),
                 ("rsfc_time", C.c_void_p), ("status", C.c_void_p), ("N", C.c_int32), ("M", C.c_int32), ("max_boxes", C.c_int32), ("npair", C.c_int32),
                 ("device", C.c_int32)]
+
+
+class rbp_solver_opts(C.Structure):
+    _fields_ = [("size", C.c_int32), ("polish", C.c_int32), ("joint_wide_min_agents", C.c_int32), ("joint_corrector", C.c_int32),
+                ("joint_schedule", C.c_int32), ("qp_schedule", C.c_int32), ("qp_variant", C.c_int32), ("qp_block_order", C.c_int32),
+                ("qp_groups", C.c_int32), ("qp_rounds", C.c_int32)]
 
 
 class rbp_mission_buf(C.Structure):

@@ -56,11 +56,20 @@ int rbp_set_error(int code, const char* msg) { return fail(code, msg); }  // for
 
 // A context owns one device arena that successive sessions (and the synchronous one-shot calls) reuse: the drop-in calls
 // rbp_corridor_update / rbp_planner_update would otherwise hipMalloc + hipFree ~10 MB per plan.
+static rbp_solver_opts default_solver_opts() {
+    rbp_solver_opts o;
+    rbp_solver_opts_defaults(&o);
+    return o;
+}
+
 struct rbp_ctx {
     int device = 0;
     char* base = nullptr;
     size_t cap = 0;
     bool busy = false;  // a live session is using the arena
+    rbp_solver_opts opts = default_solver_opts();
+    char* ws_base = nullptr;  // QP workspace of the context's sessions: reserved by the first PLANNER run that needs it, kept, grown on demand
+    size_t ws_cap = 0;
 };
 
 struct rbp_session {
@@ -70,8 +79,14 @@ struct rbp_session {
     rbp_param param{};
     Arena arena;
     rbp_ctx* ctx = nullptr;  // non-null: the arena belongs to this context
+    rbp_solver_opts opts = default_solver_opts();
+    // QP workspace: reserved by the first PLANNER run for the options then in force (not by create: a corridor-only session needs none, and
+    // the grid-wide joint solver's is large); a session's own allocation, or its context's
     void* qp_ws = nullptr;
     size_t qp_ws_per_mission = 0;
+    char* ws_own = nullptr;
+    bool ws_joint = false;    // what the workspace was laid out for
+    int bs = 1, biter = 0;    // batch schedule of the plan (setBatch, rbp_planner.hpp:849-872)
     std::vector<int> Mk, MBk;         // per-mission segments / box capacity (host copy of DevSession::Mk, MBk)
     std::vector<DevWorld> worlds_h;
     // planner-stage inputs as uploaded, in device layout (so that a run which overwrote them can be reset)
@@ -79,8 +94,7 @@ struct rbp_session {
     std::vector<double> sfc_box0, sfc_time0, rsfc_time0;
     std::vector<float> rsfc_normal0;
     bool have_corridor_inputs = false;
-    bool planner_ok = true;   // false: the batch is wider than the QP kernel supports (corridor-only session)
-    bool joint_wide = false;  // the joint QP (plan/sequential = false) runs on the grid-wide solver (kernels/jqp.hip)
+    bool joint_wide = false;  // the joint QP (plan/sequential = false) runs on the grid-wide solver (kernels/jqp.hip): decided per PLANNER run
     JointStats joint_stats{};
     // phase-split schedule of the batch QPs (kernels/qp_phase.inc): the session's missions run as up to QP_MAX_GROUPS groups on streams
     // of their own, forked from / joined into the caller's stream by events (created on first use)
@@ -103,6 +117,7 @@ size_t rbp_sizeof(int which) {
         case RBP_SIZEOF_PLAN: return sizeof(rbp_plan);
         case RBP_SIZEOF_COUNTERS: return sizeof(rbp_counters);
         case RBP_SIZEOF_DEVICE_ARRAYS: return sizeof(rbp_device_arrays);
+        case RBP_SIZEOF_SOLVER_OPTS: return sizeof(rbp_solver_opts);
         default: return 0;
     }
 }
@@ -124,6 +139,23 @@ void rbp_param_defaults(rbp_param* p) {  // param.hpp:44-70
     p->time_scale = 1, p->time_step = 1, p->downwash = 2.0;
     p->n = 5, p->phi = 3, p->sequential = 0, p->batch_size = 4, p->batch_iter = 0, p->iteration = 1;
     p->log = 0;
+}
+
+void rbp_solver_opts_defaults(rbp_solver_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->size = (int32_t)sizeof(*o);
+    o->polish = 1, o->joint_wide_min_agents = 16, o->joint_corrector = 1, o->joint_schedule = 0;
+    o->qp_schedule = 0, o->qp_variant = 0, o->qp_block_order = 1, o->qp_groups = 0, o->qp_rounds = 0;
+}
+
+static int check_solver_opts(const rbp_solver_opts* o) {
+    if (!o) return fail(RBP_ERR_BAD_ARGUMENT, "null solver options");
+    if (o->size != (int32_t)sizeof(rbp_solver_opts)) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts.size does not match this library (fill it with rbp_solver_opts_defaults)");
+    if (o->joint_wide_min_agents < 0 || o->joint_schedule < 0 || o->joint_schedule > 2 || o->qp_schedule < 0 || o->qp_schedule > 2 ||
+        !(o->qp_variant == 0 || o->qp_variant == 2 || o->qp_variant == 4) || o->qp_groups < 0 || o->qp_rounds < 0)
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts: field out of range");
+    return RBP_OK;
 }
 
 static size_t al(size_t n) { return ((n + 255) & ~size_t(255)) + 256; }
@@ -171,23 +203,6 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     }
     int bs = 1, biter = 0;
     batch_schedule(*param, N, &bs, &biter);
-    // a batch wider than the QP kernel factorises (the joint QP of a mission with more than planner_max_batch() agents) only
-    // concerns the PLANNER stage: such a session can still run the corridor (rbp_corridor_update*, the sharded corridor); the
-    // planner stage is refused in rbp_session_run and no QP workspace is reserved
-    // ... and so does a mission with more than QP_MAX_M segments: the factor chains' LDS progress words sit behind 64 per-step
-    // assembly counters (twisted_factor in kernels/qp.hip), one per step of the longer half chain, i.e. M - 1 <= 127 knots
-    // The joint QP of a mission (plan/sequential = false: one batch of all N agents) is spread over the whole chip by kernels/jqp.hip
-    // when it is wide enough to pay for a launch per phase (default: 16 agents or more, i.e. knot blocks of order >= 144; RBP_JOINT_WIDE
-    // = 0 / 1 forces the one-workgroup / the grid-wide solver).  Measured (tools/gpu_joint_sweep.py, one mission / 250 / 1000 resident):
-    // 16 agents 0.067 s against 0.283 s, 9.2 k against 8.0 k, 11.2 k against 7.4 k agent-trajectories/s; 32 agents 0.105 s against 1.6 s,
-    // and the one-workgroup polish (<= 256 candidate rows) accepts none of the 50 maps there; 8 agents: 0.038 s against 0.062 s alone but
-    // 10.6 k against 18.1 k at 250 resident -- below 16 agents a workgroup per mission stays.  It has no limit on N.
-    bool joint_wide = false;
-    if (!param->sequential && biter > 0 && N >= 2) {
-        const char* e = getenv("RBP_JOINT_WIDE");
-        joint_wide = e ? e[0] == '1' : N >= 16;
-    }
-    const bool planner_ok = joint_wide || (!(biter > 0 && bs > planner_max_batch()) && M <= QP_MAX_M);
 
     struct Guard {  // every error path below releases the session (and with it the arena)
         rbp_session* s;
@@ -201,11 +216,8 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     s->Mk.resize(K), s->MBk.resize(K);
     for (int k = 0; k < K; ++k) s->Mk[k] = plans[k].M, s->MBk[k] = plans[k].max_boxes;
     const int P = M + 1, npair = N * (N - 1) / 2, oq = 6 * M;
-    s->planner_ok = planner_ok;
-    s->joint_wide = joint_wide;
-    s->qp_ws_per_mission = !planner_ok ? 0
-                           : joint_wide ? joint_workspace_bytes(N, M)
-                                        : std::max(planner_workspace_bytes_w2(N, M, bs), planner_workspace_bytes_w4(N, M, bs));
+    s->bs = bs, s->biter = biter;
+    if (ctx) s->opts = ctx->opts;
     {
         hipDeviceProp_t prop;
         s->n_cu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -234,8 +246,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
                          al(sizeof(double) * (size_t)K * N * MB * 6) + al(sizeof(double) * (size_t)K * N * MB) +
                          al(sizeof(float) * (size_t)K * npair * M * 3 + 16) + al(sizeof(double) * K * M) +
                          2 * al(sizeof(double) * (size_t)K * N * 3 * oq) + al(sizeof(int) * K) + al(sizeof(double) * K * SC_N) +
-                         al(sizeof(unsigned long long) * K * CT_N) + al(sizeof(int) * K) + al(sizeof(unsigned long long) * K) +
-                         al(s->qp_ws_per_mission * K) + 4096;
+                         al(sizeof(unsigned long long) * K * CT_N) + al(sizeof(int) * K) + al(sizeof(unsigned long long) * K) + 4096;
     if (ctx) {
         if (ctx->busy) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: the context's arena is in use by another session");
         if (ctx->device != device) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_ctx: context belongs to another device");
@@ -275,7 +286,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
     d.p.iteration = param->iteration, d.p.time_scale = param->time_scale;
-    d.p.polish = getenv("RBP_NO_POLISH") ? 0 : 1;  // diagnostics only: interior-point answer without the active-set polish
+    d.p.polish = 1;  // (rbp_solver_opts.polish of the run)
 
     Arena& A = s->arena;
     s->worlds_h.resize(K);
@@ -320,13 +331,8 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     d.status = A.take<int>(K);
     d.scalars = A.take<double>((size_t)K * SC_N);
     d.counters = A.take<unsigned long long>((size_t)K * CT_N);
-    {
-        const char* e = getenv("RBP_QP_ORDER");  // "0": plain block order (diagnostics)
-        const bool on = !(e && e[0] == '0');
-        d.qp_order = on ? A.take<int>(K) : nullptr;
-        d.qp_cost = on ? A.take<unsigned long long>(K) : nullptr;
-    }
-    s->qp_ws = A.take<char>(s->qp_ws_per_mission * K);
+    d.qp_order = A.take<int>(K);
+    d.qp_cost = A.take<unsigned long long>(K);
     if (A.off > A.size) return fail(RBP_ERR_HIP, "arena overflow (internal sizing error)");
     bool have_corr = true;
     for (int k = 0; k < K; ++k)
@@ -411,36 +417,100 @@ int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t age
     return RBP_OK;
 }
 
-// which schedule runs the batch QPs: the phase-split one (kernels/qp_phase.inc: chip-wide row sweeps, one workgroup per mission for the
-// chains) or one workgroup per mission for everything (qp_batch_kernel)
-static bool qp_phase_split(const rbp_session* s) {
-    const char* e = getenv("RBP_QP_PATH");  // developer override (A/B runs): "phase" | "mono"
-    if (e) return e[0] == 'p';
-    return false;
+// The QP workspace of a PLANNER run.  Which solver runs -- and with it the workspace layout -- depends on the plan and on the session's
+// solver options; the workspace is reserved here, by the first run that needs it (a corridor-only session reserves nothing), in the
+// session's own allocation or its context's (kept across the context's sessions, grown on demand), and cleared once.
+static int ensure_planner_workspace(rbp_session* s, hipStream_t st) {
+    const DevSession& d = s->d;
+    const int N = d.N, M = d.M, K = d.K;
+    const rbp_solver_opts& o = s->opts;
+    // The joint QP of a mission (plan/sequential = false: one batch of all N agents) is spread over the whole chip by kernels/jqp.hip when it
+    // is wide enough to pay for a launch per phase (default: 16 agents or more, i.e. knot blocks of order >= 144).  Measured
+    // (tools/gpu_joint_sweep.py, one mission / 250 / 1000 resident): 16 agents 0.067 s against 0.283 s, 9.2 k against 8.0 k, 11.2 k against
+    // 7.4 k agent-trajectories/s; 32 agents 0.105 s against 1.6 s, and the one-workgroup polish (<= 256 candidate rows) accepts none of the 50
+    // maps there; 8 agents: 0.038 s against 0.062 s alone but 10.6 k against 18.1 k at 250 resident -- below 16 agents a workgroup per mission
+    // stays.  The grid-wide solver has no limit on N.
+    const bool joint_wide = !s->param.sequential && s->biter > 0 && N >= 2 && o.joint_wide_min_agents > 0 && N >= o.joint_wide_min_agents;
+    if (!joint_wide) {
+        // a batch wider than the one-workgroup kernel factorises (the joint QP of a mission with more than planner_max_batch() agents), or a
+        // mission with more than QP_MAX_M segments (the factor chains' LDS progress words sit behind 64 per-step assembly counters)
+        if (M > QP_MAX_M) return fail(RBP_ERR_BAD_ARGUMENT, "more than " + std::to_string(QP_MAX_M) + " segments per mission are not supported by the QP kernel");
+        if (s->biter > 0 && s->bs > planner_max_batch())
+            return fail(RBP_ERR_BAD_ARGUMENT, "batch wider than " + std::to_string(planner_max_batch()) +
+                                                  " agents (joint QP of a large mission) is not supported by the one-workgroup QP kernel "
+                                                  "(rbp_solver_opts.joint_wide_min_agents selects the grid-wide solver)");
+    }
+    const size_t per = joint_wide ? joint_workspace_bytes(N, M) : std::max(planner_workspace_bytes_w2(N, M, s->bs), planner_workspace_bytes_w4(N, M, s->bs));
+    s->joint_wide = joint_wide;
+    if (s->qp_ws && s->ws_joint == joint_wide && s->qp_ws_per_mission == per) return RBP_OK;
+    const size_t total = per * (size_t)K + 256;
+    auto too_large = [&](hipError_t e) {
+        return fail(RBP_ERR_HIP, "QP workspace: " + std::to_string(total) + " bytes (" + std::to_string(K) + " missions x " + std::to_string(per) +
+                                     " bytes for " + (joint_wide ? "the grid-wide joint solver" : "the batch QP kernels") + ") could not be reserved: " +
+                                     hipGetErrorString(e));
+    };
+    char* base = nullptr;
+    if (s->ctx) {
+        rbp_ctx* c = s->ctx;
+        if (c->ws_cap < total) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c->ws_base) (void)hipFree(c->ws_base);
+            c->ws_base = nullptr, c->ws_cap = 0;
+            const size_t want = total + total / 4;
+            hipError_t e = hipMalloc((void**)&c->ws_base, want);
+            if (e != hipSuccess) return too_large(e);
+            c->ws_cap = want;
+        }
+        base = c->ws_base;
+    } else {
+        if (s->ws_own) {
+            HIP_TRY(hipStreamSynchronize(st));
+            (void)hipFree(s->ws_own);
+            s->ws_own = nullptr;
+        }
+        hipError_t e = hipMalloc((void**)&s->ws_own, total);
+        if (e != hipSuccess) return too_large(e);
+        base = s->ws_own;
+    }
+    HIP_TRY(hipMemsetAsync(base, 0, total, st));
+    s->qp_ws = base, s->qp_ws_per_mission = per, s->ws_joint = joint_wide;
+    return RBP_OK;
+}
+
+int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    int rc = check_solver_opts(o);
+    if (rc) return rc;
+    s->opts = *o;
+    return RBP_OK;
 }
 
 int rbp_session_run(rbp_session* s, int stages, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
-    if ((stages & RBP_STAGE_PLANNER) && !s->planner_ok)
-        return fail(RBP_ERR_BAD_ARGUMENT, s->d.M > QP_MAX_M
-                                              ? "more than " + std::to_string(QP_MAX_M) + " segments per mission are not supported by the QP kernel"
-                                              : "batch wider than " + std::to_string(planner_max_batch()) +
-                                                    " agents (joint QP of a large mission) is not supported by the QP kernel");
+    const rbp_solver_opts& o = s->opts;
+    if (stages & RBP_STAGE_PLANNER) {
+        int rc = ensure_planner_workspace(s, st);
+        if (rc) return rc;
+    }
     s->last_stages = stages;
+    s->d.p.polish = o.polish ? 1 : 0;
     if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
     if ((stages & RBP_STAGE_PLANNER) && s->joint_wide) {
         // grid-wide joint QP: a launch per phase; the host learns once per interior-point iteration whether any mission is still
         // running, so this call SYNCHRONISES the stream (unlike the batch path, which only enqueues)
         launch_planner_prologue(s->d, st);
         int rc = RBP_OK;
-        if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats);
+        JointOpts jo;
+        jo.corrector = o.joint_corrector ? 1 : 0, jo.schedule = o.joint_schedule;
+        if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats, jo);
         if (rc) return fail(rc, "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
-    } else if ((stages & RBP_STAGE_PLANNER) && qp_phase_split(s)) {
-        const char* ge = getenv("RBP_QP_GROUPS");  // developer override (A/B runs)
-        int G = ge ? atoi(ge) : (s->d.K >= 1024 ? 4 : (s->d.K >= 256 ? 2 : 1));
+    } else if ((stages & RBP_STAGE_PLANNER) && o.qp_schedule == 2) {
+        // phase split (kernels/qp_phase.inc): chip-wide row sweeps, one workgroup per mission for the chains; the missions are spread over a
+        // few streams whose rounds overlap
+        int G = o.qp_groups > 0 ? o.qp_groups : (s->d.K >= 1024 ? 2 : 1);
         G = std::max(1, std::min(G, std::min((int)rbp_session::QP_MAX_GROUPS, s->d.K)));
         while (s->n_gstream < G) {
             const int g = s->n_gstream;
@@ -449,17 +519,18 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
             HIP_TRY(hipEventCreateWithFlags(&s->gevent[1 + g], hipEventDisableTiming));
             s->n_gstream++;
         }
-        const char* re = getenv("RBP_QP_ROUNDS");  // developer override: round budget
-        launch_planner_phased(s->d, s->qp_ws, s->qp_ws_per_mission, st, s->gstream, s->gevent, G, re ? atoi(re) : 0);
+        launch_planner_phased(s->d, s->qp_ws, s->qp_ws_per_mission, st, s->gstream, s->gevent, G, o.qp_rounds);
     } else if (stages & RBP_STAGE_PLANNER) {
-        // two workgroups per CU (the 128-VGPR build) pay off as soon as there are more missions than CUs: the 256-VGPR build
-        // would need a second round (measured at 300/400/500 missions: +17-21 %)
-        const char* force = getenv("RBP_QP_VARIANT");  // developer override: "w2" | "w4"
-        const bool w4 = force ? (force[0] == 'w' && force[1] == '4') : s->d.K > s->n_cu;
+        // one workgroup per mission (qp_batch_kernel; the default: see DESIGN.md 3.3 for the A/B against the phase split).  Two workgroups
+        // per CU (the 256-thread build) pay off as soon as there are more missions than CUs: the 512-thread build would need a second round
+        // (measured at 300/400/500 missions: +17-21 %)
+        const bool w4 = o.qp_variant ? o.qp_variant == 4 : s->d.K > s->n_cu;
+        DevSession d = s->d;
+        if (!o.qp_block_order) d.qp_order = nullptr, d.qp_cost = nullptr;
         if (w4)
-            launch_planner_w4(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+            launch_planner_w4(d, s->qp_ws, s->qp_ws_per_mission, st);
         else
-            launch_planner_w2(s->d, s->qp_ws, s->qp_ws_per_mission, st);
+            launch_planner_w2(d, s->qp_ws, s->qp_ws_per_mission, st);
     }
     HIP_TRY(hipGetLastError());
     return RBP_OK;
@@ -602,8 +673,12 @@ void rbp_session_destroy(rbp_session* s) {
         (void)hipEventDestroy(s->gevent[0]);
         for (int g = 0; g < s->n_gstream; ++g) (void)hipStreamDestroy(s->gstream[g]), (void)hipEventDestroy(s->gevent[1 + g]);
     }
+    if (s->ws_own) {
+        (void)hipSetDevice(s->device);
+        (void)hipFree(s->ws_own);
+    }
     if (s->ctx) {
-        s->ctx->busy = false;  // the arena stays with the context
+        s->ctx->busy = false;  // the arena (and the QP workspace) stay with the context
     } else if (s->arena.base) {
         (void)hipSetDevice(s->device);
         (void)hipFree(s->arena.base);
@@ -628,9 +703,10 @@ int rbp_ctx_create(rbp_ctx** out, int device) {
 
 void rbp_ctx_destroy(rbp_ctx* c) {
     if (!c) return;
-    if (c->base) {
+    if (c->base || c->ws_base) {
         (void)hipSetDevice(c->device);
-        (void)hipFree(c->base);
+        if (c->base) (void)hipFree(c->base);
+        if (c->ws_base) (void)hipFree(c->ws_base);
     }
     delete c;
 }
@@ -685,6 +761,7 @@ static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mis
     if (!ctx) {
         int dev = 0;
         (void)hipGetDevice(&dev);
+        rbp_solver_opts keep = tls.c ? tls.c->opts : default_solver_opts();
         if (tls.c && tls.c->device != dev) {
             rbp_ctx_destroy(tls.c);
             tls.c = nullptr;
@@ -692,6 +769,7 @@ static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mis
         if (!tls.c) {
             int rc = rbp_ctx_create(&tls.c, dev);
             if (rc) return rc;
+            tls.c->opts = keep;
         }
         ctx = tls.c;
     }
@@ -706,6 +784,24 @@ static int one_shot(rbp_ctx* ctx, const rbp_world* world, const rbp_mission* mis
     }
     rbp_session_destroy(s);
     return rc;
+}
+
+int rbp_ctx_set_solver_opts(rbp_ctx* ctx, const rbp_solver_opts* o) {
+    int rc = check_solver_opts(o);
+    if (rc) return rc;
+    if (!ctx) {  // the calling thread's default context
+        Tls& tls = tls_ctx();
+        if (!tls.c) {
+            int ndev = 0, dev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RBP_ERR_NO_DEVICE, "no HIP device: the RBP path has no CPU fallback");
+            (void)hipGetDevice(&dev);
+            rc = rbp_ctx_create(&tls.c, dev);
+            if (rc) return rc;
+        }
+        ctx = tls.c;
+    }
+    ctx->opts = *o;
+    return RBP_OK;
 }
 
 int rbp_corridor_update(const rbp_world* world, const rbp_mission* mission, const rbp_param* param, rbp_plan* plan) {

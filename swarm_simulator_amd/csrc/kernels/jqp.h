@@ -28,6 +28,8 @@ struct JArgs {
     double gond[3];  // centrality corrector: extra step length asked for, share of it that must be gained, step length below which it is tried
     double early_mu[2];  // complementarity below which the first / the second early polish attempt is made
     double pol_tau;  // polish: a pivot of S_AA below pol_tau x the row's own diagonal marks a row that depends on the rows before it (deleted from that solve)
+    double pol_vtol;  // experiment: row violation accepted after the last refinement round
+    int pol_adtau;   // experiment: adaptive deletion threshold on/off
     double exit_mu;  // third exit of the interior-point loop: pres < 1e-9, dres < 1e-7, mu < exit_mu
     double pol_lh_early, pol_lh_final;  // block Lawson-Hanson rounds allowed in an early / the final polish attempt
     double tune[5];  // mu0, slack floor, centring exponent, neighbourhood gamma, step fraction
@@ -38,9 +40,14 @@ struct JointStats {
     int polish_rounds;  // active-set rounds of the polish
 };
 
+struct JointOpts {  // what rbp_solver_opts says about the grid-wide joint solver
+    int corrector = 1;  // one centrality corrector per interior-point iteration
+    int schedule = 0;   // tile sweep: 0 automatic, 1 look-ahead, 2 bulk
+};
+
 JLayout jq_layout(int N, int MS);
 size_t joint_workspace_bytes(int N, int MS);
 // dummy_kernel .. timescale_kernel around it are launched by the caller (launch_planner_prologue / _epilogue in qp.hip)
-int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats);
+int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats, const JointOpts& opts);
 void launch_planner_prologue(const DevSession& s, hipStream_t st);
 void launch_planner_epilogue(const DevSession& s, hipStream_t st);

@@ -60,7 +60,11 @@ enum { ST_STATE = 0 /* 0 running, 1 converged, 2 failed */, ST_ITER, ST_PAR /* w
        ST_GACT /* centrality corrector: this mission tries one */, ST_GOK /* ... and took it: dx and the rows' target shifts T are in force */,
        ST_ATR /* trial step length */, ST_AP /* step length of the Mehrotra direction */,
        ST_PACC /* the iterate before the last step was acceptable (pres < 1e-9, dres < 1e-7, mu < 5e-8) */, ST_PMU, ST_PPRES, ST_PDRES,
-       ST_REVERT /* the last step is being taken back (jq_unstep) */, ST_N = 40 };
+       ST_REVERT /* the last step is being taken back (jq_unstep) */,
+       ST_PTAU /* polish: this mission's deletion threshold is pol_tau * ST_PTAU (1, tightened by jp_check when a deleted row does not verify) */,
+       ST_CONT /* continuations: final polish attempts refused so far, each followed by another decade of the interior-point method */,
+       ST_N = 40 };
+constexpr int JQ_MAX_CONT = 3;  // the exit threshold of a mission is exit_mu * 10^-ST_CONT: 1e-9, then 1e-10, 1e-11, 1e-12
 // reduction slots (each [4 components][nred workgroups])
 enum { RS_BUILD = 0 /* sum0 = gap, vmax = pres */, RS_POST /* dmax, gmax */, RS_AFF /* vmax, sum0, sum1, sum2 */, RS_STEP /* vmax */,
        RS_UP /* vmin */, RS_INIT /* pinned-row violation */, RS_VERIFY /* polish: worst violation at the trial point */, RS_NSLOT };
@@ -759,8 +763,15 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             // the exits of qp.hip, the third one at mu < 1e-9 instead of 1e-14: the explicit inverses of this solver put a floor under the
             // dual residual that RISES with the Newton weights (1e-9 .. 1e-5 once mu < 1e-10, even with two refinement steps per solve),
             // so going on only loses accuracy; what turns this iterate into the optimum is the active-set polish, not more iterations
-            const bool ok = (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
-                            (pres < 1e-9 && dres < 1e-7 && mu < A.exit_mu);
+            // CONTINUATION (round 5).  A final polish attempt that is refused does not end the mission any more: the iterate is untouched, so
+            // the interior-point method goes on for another decade of mu (exit threshold exit_mu * 10^-ST_CONT) and the polish is tried
+            // again on the sharper iterate -- the candidate set of a mu = 1e-10 iterate holds fewer rows that merely look active --, up to
+            // JQ_MAX_CONT times; the safeguard below still takes back a step that loses the dual residual, and that ends the mission.
+            const int cont = (int)st[ST_CONT];
+            const double exit_mu = A.exit_mu * (cont == 0 ? 1.0 : (cont == 1 ? 1e-1 : (cont == 2 ? 1e-2 : 1e-3)));
+            const bool ok = cont == 0 ? (pres < 1e-9 && dres < 1e-9 && mu < 1e-10) || (pres < 1e-6 && dres < 1e-9 && mu < 1e-13) ||
+                                            (pres < 1e-9 && dres < 1e-7 && mu < exit_mu)
+                                      : (pres < 1e-9 && dres < 1e-7 && mu < exit_mu);
             const bool polish_on = S.p.polish != 0;
             // SAFEGUARD.  Past mu ~ 1e-8 a step can cost the dual residual five orders of magnitude (explicit inverses at Newton weights
             // of 1e9: 5e-9 -> 1e-5 -> 1e-2 in two iterations, after which the method crawls for a hundred iterations or never returns).
@@ -769,6 +780,7 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
             // (final polish attempt, else unpolished with its own residuals).
             const bool lost = !ok && st[ST_PACC] != 0.0 && (dres >= 1e-7 || dres > 100.0 * st[ST_PDRES]);
             if (lost) {
+                st[ST_CONT] = JQ_MAX_CONT;  // (no continuation from a step that was taken back)
                 st[ST_REVERT] = 1.0, st[ST_PAR] = 1.0 - st[ST_PAR];
                 st[ST_MU] = st[ST_PMU], st[ST_PRES] = st[ST_PPRES], st[ST_DRES] = st[ST_PDRES];
                 st[ST_KKT] = fmax(st[ST_PPRES], fmax(st[ST_PDRES], st[ST_PMU]));
@@ -1113,7 +1125,7 @@ __global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int m
     const double* tkk = c.src + ((size_t)k * c.nblk + k) * JTT;  // pivot tile (k, k) as the steps before k left it
     for (int i = threadIdx.x; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = tkk[i];
     __shared__ double thr[JT];
-    if (c.G && threadIdx.x < JT) thr[threadIdx.x] = A.pol_tau * c.G[((size_t)k * c.nblk + k) * JTT + (size_t)threadIdx.x * (JT + 1)];
+    if (c.G && threadIdx.x < JT) thr[threadIdx.x] = A.pol_tau * w.st[ST_PTAU] * c.G[((size_t)k * c.nblk + k) * JTT + (size_t)threadIdx.x * (JT + 1)];
     __syncthreads();
     inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
     store_pivot_inverse(Am, c.Pk);
@@ -1264,7 +1276,7 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
     }
     if (look) {
         __shared__ double thr[JT];
-        if (c.G && tid < JT) thr[tid] = A.pol_tau * c.G[((size_t)(k + 1) * nblk + (k + 1)) * JTT + (size_t)tid * (JT + 1)];
+        if (c.G && tid < JT) thr[tid] = A.pol_tau * w.st[ST_PTAU] * c.G[((size_t)(k + 1) * nblk + (k + 1)) * JTT + (size_t)tid * (JT + 1)];
         __syncthreads();
         inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
         store_pivot_inverse(Am, c.Pn);
@@ -1559,20 +1571,41 @@ size_t joint_workspace_bytes(int N, int MS) { return jq_layout(N, MS).stride * s
 
 // One joint QP per mission of the session.  Synchronises the stream once per interior-point iteration (to learn whether any mission is
 // still running); everything else is enqueued.
-int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats) {
+int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointStats* stats, const JointOpts& opts) {
     JArgs A;
     A.S = s, A.ws = (double*)ws, A.L = jq_layout(s.N, s.M);
+    // Solver constants (what each one does: jqp.h JArgs).  They are compiled in: the library reads no environment variables
+    // (rbp_solver_opts carries the switches a caller may set).  The developer build (-DRBP_DEV_KNOBS, `make dev`) lets experiments override
+    // them from the environment (tools/joint_env_sweep.sh).
+    A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0, A.gond_only = 0;
+    A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
+    A.pol_lh_early = 60, A.pol_lh_final = 160;
+    A.gond[0] = 0.3, A.gond[1] = 0.1, A.gond[2] = 0.9;
+    // (qp.hip tries at 1e-6 and 1e-8; here the candidate set of a mu = 1e-6 iterate is thousands of rows away from the active set -- the
+    // attempt costs more than an iteration and never succeeded on the 50 maps --, so ONE early attempt at 1e-8: 3.07 -> 2.64 s per sweep)
+    A.early_mu[0] = 1e-8, A.early_mu[1] = 0.0;
+    A.pol_tau = 2e-7, A.pol_vtol = 5e-8, A.pol_adtau = 1, A.exit_mu = 1e-9;
+    int pol_wait = 8;
+    int sched = opts.schedule, gondzio = opts.corrector ? 1 : 0;
+    bool trace = false;
+#ifdef RBP_DEV_KNOBS
     {
-        const char* e = getenv("RBP_JQ_DREG");  // experiments: "mode,scale,max"
-        A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0, A.gond_only = 0;
+        const char* e = getenv("RBP_JQ_DREG");  // "mode,scale,max"
         if (e) sscanf(e, "%d,%lf,%lf", &A.dreg_mode, &A.dreg_scale, &A.dreg_max);
-        A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
-        A.pol_lh_early = 60, A.pol_lh_final = 160;
-        const char* pl = getenv("RBP_JQ_LH");  // experiments: "early,final" round caps of the polish's Lawson-Hanson fallback
-        if (pl) sscanf(pl, "%lf,%lf", &A.pol_lh_early, &A.pol_lh_final);
-        const char* t = getenv("RBP_JQ_TUNE");  // experiments: "mu0,sfloor,sigma exponent,neighbourhood gamma,step fraction"
-        if (t) sscanf(t, "%lf,%lf,%lf,%lf,%lf", &A.tune[0], &A.tune[1], &A.tune[2], &A.tune[3], &A.tune[4]);
+        if ((e = getenv("RBP_JQ_LH"))) sscanf(e, "%lf,%lf", &A.pol_lh_early, &A.pol_lh_final);  // round caps of the polish's Lawson-Hanson fallback
+        if ((e = getenv("RBP_JQ_TUNE"))) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &A.tune[0], &A.tune[1], &A.tune[2], &A.tune[3], &A.tune[4]);
+        if ((e = getenv("RBP_JQ_GOND"))) sscanf(e, "%lf,%lf,%lf", &A.gond[0], &A.gond[1], &A.gond[2]);
+        if ((e = getenv("RBP_JQ_EARLY"))) sscanf(e, "%lf,%lf", &A.early_mu[0], &A.early_mu[1]);
+        if ((e = getenv("RBP_JQ_POLTAU"))) A.pol_tau = atof(e);
+        if ((e = getenv("RBP_JQ_VTOL"))) A.pol_vtol = atof(e);
+        if ((e = getenv("RBP_JQ_ADTAU"))) A.pol_adtau = atoi(e);
+        if ((e = getenv("RBP_JQ_EXITMU"))) A.exit_mu = atof(e);
+        if ((e = getenv("RBP_JQ_POLWAIT"))) pol_wait = atoi(e);
+        if ((e = getenv("RBP_JQ_SCHED"))) sched = e[0] == 'b' ? 2 : 1;
+        if ((e = getenv("RBP_JQ_GONDZIO"))) gondzio = atoi(e) != 0;
+        trace = getenv("RBP_JOINT_TRACE") != nullptr;
     }
+#endif
     const JLayout& L = A.L;
     const int K = s.K, N = s.N;
     const JDims dm = jdims(N, s.M);  // the session's largest mission
@@ -1618,17 +1651,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // two schedules of the sweep: look-ahead (the workgroup that updates the next pivot tile inverts it: one dependent launch less per
     // step -- a lone mission is bound by that chain) / bulk (thousands of tiles per launch: a leaner update kernel at three workgroups per
     // CU, the pivot inverse in a launch of its own)
-    const char* be = getenv("RBP_JQ_SCHED");  // "look" | "bulk" (A/B runs: tools/joint_sched_ab.sh)
-    const bool bulk = be ? be[0] == 'b' : K >= 8 && (size_t)K * 2 * ntri >= 1024;
-    const int gondzio = getenv("RBP_JQ_GONDZIO") ? atoi(getenv("RBP_JQ_GONDZIO")) != 0 : 1;
-    A.gond[0] = 0.3, A.gond[1] = 0.1, A.gond[2] = 0.9;
-    if (getenv("RBP_JQ_GOND")) sscanf(getenv("RBP_JQ_GOND"), "%lf,%lf,%lf", &A.gond[0], &A.gond[1], &A.gond[2]);  // experiments
-    // (qp.hip tries at 1e-6 and 1e-8; here the candidate set of a mu = 1e-6 iterate is thousands of rows away from the active set -- the
-    // attempt costs more than an iteration and never succeeded on the 50 maps --, so ONE early attempt at 1e-8: 3.07 -> 2.64 s per sweep)
-    A.early_mu[0] = 1e-8, A.early_mu[1] = 0.0;
-    if (getenv("RBP_JQ_EARLY")) sscanf(getenv("RBP_JQ_EARLY"), "%lf,%lf", &A.early_mu[0], &A.early_mu[1]);  // experiments
-    A.pol_tau = getenv("RBP_JQ_POLTAU") ? atof(getenv("RBP_JQ_POLTAU")) : 2e-7;
-    A.exit_mu = getenv("RBP_JQ_EXITMU") ? atof(getenv("RBP_JQ_EXITMU")) : 1e-9;
+    const bool bulk = sched ? sched == 2 : K >= 8 && (size_t)K * 2 * ntri >= 1024;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
@@ -1642,7 +1665,6 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                 JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
         }
     };
-    const bool trace = getenv("RBP_JOINT_TRACE") != nullptr;
     A.trace = trace ? 1 : 0;
     // ---- active-set polish of the missions whose control kernel asked for it (jqp_polish.inc); host-driven state machine, one
     // synchronisation per stage
@@ -1729,7 +1751,6 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         return RBP_OK;
     };
     int iters = 0, rc = RBP_OK, go_waited = 0;
-    const int pol_wait = getenv("RBP_JQ_POLWAIT") ? atoi(getenv("RBP_JQ_POLWAIT")) : 8;
     const int max_rounds = JQ_MAX_ITERS + 48;
     for (int it = 0; it < max_rounds; ++it) {
         if (it == 0) JQ_LAUNCH(jq_sweep<PASS_BUILD>, dim3(nsw, K), 0, A);

@@ -77,7 +77,7 @@ def lib():
             if L.rbp_abi_version() != A.RBP_ABI_VERSION:
                 raise RbpLibraryMissing(f"{path}: ABI version {L.rbp_abi_version()}, this binding expects {A.RBP_ABI_VERSION} (rebuild the library)")
             L.rbp_session_device_arrays.argtypes = [C.c_void_p, C.c_int32, P(A.rbp_device_arrays)]
-            for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters, A.rbp_device_arrays)):
+            for which, t in enumerate((A.rbp_world, A.rbp_mission, A.rbp_param, A.rbp_plan, A.rbp_counters, A.rbp_device_arrays, A.rbp_solver_opts)):
                 if L.rbp_sizeof(which) != C.sizeof(t):
                     raise RbpLibraryMissing(f"{path}: sizeof({t.__name__}) is {L.rbp_sizeof(which)} in the library, {C.sizeof(t)} in this binding")
             L.rbp_release_thread_context.restype = None
@@ -104,6 +104,10 @@ def lib():
         except AttributeError:
             if not os.environ.get("RBP_HIP_LIB"):
                 raise
+        L.rbp_solver_opts_defaults.argtypes = [P(A.rbp_solver_opts)]
+        L.rbp_solver_opts_defaults.restype = None
+        L.rbp_session_set_solver_opts.argtypes = [C.c_void_p, P(A.rbp_solver_opts)]
+        L.rbp_ctx_set_solver_opts.argtypes = [C.c_void_p, P(A.rbp_solver_opts)]
         L.rbp_ctx_create.argtypes = [P(C.c_void_p), C.c_int]
         L.rbp_ctx_destroy.argtypes = [C.c_void_p]
         L.rbp_ctx_destroy.restype = None
@@ -125,6 +129,7 @@ EXPORTED_SYMBOLS = [
     "rbp_last_error", "rbp_device_count",
     "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
     "rbp_session_create_in",
+    "rbp_solver_opts_defaults", "rbp_session_set_solver_opts", "rbp_ctx_set_solver_opts",
     "rbp_edt_dims", "rbp_edt_build",
 ]
 
@@ -133,14 +138,44 @@ def last_error():
     return lib().rbp_last_error().decode()
 
 
-class Context:
-    """rbp_ctx: device memory kept across plans (include/rbp.h).  `device=None` = the calling thread's current device."""
+def solver_opts(**kw):
+    """rbp_solver_opts (include/rbp.h) with the library's defaults, fields overridden by keyword: polish, joint_wide_min_agents,
+    joint_corrector, joint_schedule (0 auto / 1 look-ahead / 2 bulk), qp_schedule (0 auto / 1 one workgroup per mission / 2 phase split),
+    qp_variant (0 / 2 / 4), qp_block_order, qp_groups, qp_rounds.  The library reads no environment variables: these are the switches."""
+    o = A.rbp_solver_opts()
+    lib().rbp_solver_opts_defaults(C.byref(o))
+    for k, v in kw.items():
+        if k == "size" or not hasattr(o, k):
+            raise TypeError(f"rbp_solver_opts has no field {k!r}")
+        setattr(o, k, int(v))
+    return o
 
-    def __init__(self, device=None):
+
+def set_default_solver_opts(opts=None, **kw):
+    """solver options of the calling thread's default context: what Corridor / RBPPlanner without an explicit Context use."""
+    o = opts if opts is not None else solver_opts(**kw)
+    rc = lib().rbp_ctx_set_solver_opts(None, C.byref(o))
+    if rc:
+        raise RuntimeError(f"rbp_ctx_set_solver_opts rc={rc}: {last_error()}")
+
+
+class Context:
+    """rbp_ctx: device memory kept across plans (include/rbp.h).  `device=None` = the calling thread's current device.
+    `opts`: rbp_solver_opts (see solver_opts()) of every session / one-shot call made in the context."""
+
+    def __init__(self, device=None, opts=None):
         self._h = C.c_void_p()
         rc = lib().rbp_ctx_create(C.byref(self._h), -1 if device is None else int(device))
         if rc:
             raise RuntimeError(f"rbp_ctx_create failed rc={rc}: {ERROR_TEXT.get(rc, '')} | {last_error()}")
+        if opts is not None:
+            self.set_solver_opts(opts)
+
+    def set_solver_opts(self, opts=None, **kw):
+        o = opts if opts is not None else solver_opts(**kw)
+        rc = lib().rbp_ctx_set_solver_opts(self._h, C.byref(o))
+        if rc:
+            raise RuntimeError(f"rbp_ctx_set_solver_opts rc={rc}: {last_error()}")
 
     def plan_update(self, world: World, mission: Mission, param: Param, plan: PlanResult) -> int:
         """Corridor::update && RBPPlanner::update in one call; returns the C ABI's code (0 = both true)."""
@@ -211,7 +246,7 @@ class Session:
     """K independent missions resident in HBM (e.g. the 50-map sweep of swarm_traj_planner_rbp_test_all.cpp:49-103).
     The missions share N; every plan keeps its own M (= ECBS makespan + 2) and max_boxes."""
 
-    def __init__(self, worlds, missions, param: Param, plans, device=0):
+    def __init__(self, worlds, missions, param: Param, plans, device=0, opts=None):
         K = len(plans)
         assert len(worlds) == K and len(missions) == K
         self.K, self.plans, self.param = K, plans, param
@@ -224,6 +259,15 @@ class Session:
         rc = lib().rbp_session_create(C.byref(self._h), device, K, self._w, self._m, C.byref(self._p), self._pl)
         if rc:
             raise RuntimeError(f"rbp_session_create failed rc={rc}: {ERROR_TEXT.get(rc, '')} | {last_error()}")
+        if opts is not None:
+            self.set_solver_opts(opts)
+
+    def set_solver_opts(self, opts=None, **kw):
+        """rbp_solver_opts of this session (before its next run): Session.set_solver_opts(qp_schedule=2) or an object from solver_opts()"""
+        o = opts if opts is not None else solver_opts(**kw)
+        rc = lib().rbp_session_set_solver_opts(self._h, C.byref(o))
+        if rc:
+            raise RuntimeError(f"rbp_session_set_solver_opts rc={rc}: {last_error()}")
 
     def run(self, stages=A.RBP_STAGE_ALL, stream=None):
         rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))

@@ -223,20 +223,21 @@ def test_sweep_driver_serial_and_batched(capsys):
 
 
 @pytest.mark.parametrize("name", ["c2_16agents_map3", "s8_map5_seq4_iter2", "c3_64agents_map1"])
-def test_both_kernel_builds_agree(monkeypatch, name):
+def test_both_kernel_builds_agree(name):
     """the QP kernel is built twice (256 VGPRs, one workgroup per CU / 128 VGPRs, two per CU; csrc/Makefile) and picked per
     launch by the number of resident missions: both must land on the same certified optimum"""
     c = Case(name)
     out = {}
     for variant in ("w2", "w4"):
-        monkeypatch.setenv("RBP_QP_VARIANT", variant)
+        ctx = planner.Context(opts=planner.solver_opts(qp_variant=int(variant[1])))
         if c.g["rsfc_normal"].size:
             pr = c.with_corridor()
         else:  # the big golden stores only a hash of the RSFC normals: build the corridor on the GPU
             pr = c.inputs()
             assert planner.Corridor(c.world, c.mission, c.param).update(False, pr)
-        pl = planner.RBPPlanner(c.mission, c.param)
+        pl = planner.RBPPlanner(c.mission, c.param, ctx)
         assert pl.update(False, pr), pl.last_error
+        ctx.close()
         assert np.abs(pr.ctrl - c.g["ctrl"]).max() < CTRL_TOL
         out[variant] = pr.ctrl.copy()
     assert np.abs(out["w2"] - out["w4"]).max() < 1e-7

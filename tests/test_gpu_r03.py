@@ -99,23 +99,24 @@ def test_mixed_radius_corridor_bit_exact_and_qp_vs_oracle():
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
 
 
-def test_corridor_only_session_with_a_joint_batch_wider_than_the_qp_kernel(monkeypatch):
+def test_corridor_only_session_with_a_joint_batch_wider_than_the_qp_kernel():
     """plan/sequential=false is the reference's code default (param.hpp:67): setBatch makes one batch of all N agents.  For N above
     the ONE-WORKGROUP QP kernel's widest batch the PLANNER stage of that solver is refused -- but Corridor::update has nothing to do with
-    the batch width.  (Since round 4 such a joint QP runs on the grid-wide solver, tests/test_gpu_joint.py; RBP_JOINT_WIDE=0 asks for the
-    one-workgroup kernel.)"""
-    monkeypatch.setenv("RBP_JOINT_WIDE", "0")
+    the batch width.  (Since round 4 such a joint QP runs on the grid-wide solver, tests/test_gpu_joint.py; rbp_solver_opts.
+    joint_wide_min_agents = 0 asks for the one-workgroup kernel.)  A corridor-only call reserves no QP workspace at all."""
+    ctx = planner.Context(opts=planner.solver_opts(joint_wide_min_agents=0))
     p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
     m = host.load_mission("mission_256agents_c4.json")
     w = host.load_world("map1.bt", p)
     init = host.ecbs_plan(w, m, p)
     ref, gpu = init.clone_inputs(), init.clone_inputs()
     assert O.corridor_update(w, m, p, ref)[0] == 0
-    cor = planner.Corridor(w, m, p)
+    cor = planner.Corridor(w, m, p, ctx)
     assert cor.update(False, gpu), cor.last_error
     assert np.array_equal(ref.sfc_box, gpu.sfc_box) and np.array_equal(bits(ref.rsfc_normal), bits(gpu.rsfc_normal))
-    pl = planner.RBPPlanner(m, p)
+    pl = planner.RBPPlanner(m, p, ctx)
     assert pl.update(False, gpu) is False and pl.rc == A.RBP_ERR_BAD_ARGUMENT and "batch wider" in pl.last_error
+    ctx.close()
 
 
 def test_corridor_only_run_after_a_planner_run_is_not_time_scaled():
@@ -193,7 +194,7 @@ def test_joint_qp_32_agents_block_order_288_vs_oracle():
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
 
 
-def test_longest_first_block_order_does_not_change_results(monkeypatch):
+def test_longest_first_block_order_does_not_change_results():
     """a session that is run again starts the missions that took longest in the previous run first (DevSession::qp_order); every mission
     is a workgroup of its own, so the plans must be bit-identical to the first run's and to a session with the order switched off"""
     p = Param.test_sweep()
@@ -202,9 +203,9 @@ def test_longest_first_block_order_does_not_change_results(monkeypatch):
     worlds = [host.load_world(f, p) for f in maps]
     inits = [host.ecbs_plan(w, m, p) for w in worlds]
 
-    def run(times):
+    def run(times, **opts):
         plans = [g.clone_inputs() for g in inits]
-        sess = planner.Session(worlds, [m] * len(maps), p, plans)
+        sess = planner.Session(worlds, [m] * len(maps), p, plans, opts=planner.solver_opts(**opts))
         outs = []
         for _ in range(times):
             sess.run(A.RBP_STAGE_ALL)
@@ -214,8 +215,7 @@ def test_longest_first_block_order_does_not_change_results(monkeypatch):
         return outs
 
     first, second, third = run(3)
-    monkeypatch.setenv("RBP_QP_ORDER", "0")
-    (plain,) = run(1)
+    (plain,) = run(1, qp_block_order=0)
     for a, b, c, d in zip(first, second, third, plain):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a.view(np.uint64), c.view(np.uint64))
         assert np.array_equal(a.view(np.uint64), d.view(np.uint64))
