@@ -271,6 +271,12 @@ def main():
     ap.add_argument("--batch-size", type=int, default=4, help="plan/batch_size (4 = plan_rbp_test.launch; 8 = BASELINE config C5)")
     ap.add_argument("--iteration", type=int, default=1, help="plan/iteration: Gauss-Seidel passes over all batches (C5: 50)")
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
+    ap.add_argument("--qp-schedule", choices=["auto", "mono", "phase"], default="auto",
+                    help="rbp_solver_opts.qp_schedule: one workgroup per mission runs a mission's whole schedule (mono = the default) / the "
+                         "phase-split schedule with chip-wide row sweeps (kernels/qp_phase.inc); A/B runs")
+    ap.add_argument("--qp-groups", type=int, default=0, help="rbp_solver_opts.qp_groups (phase split: streams)")
+    ap.add_argument("--qp-variant", choices=["auto", "w2", "w4"], default="auto", help="rbp_solver_opts.qp_variant (A/B runs)")
+    ap.add_argument("--plain-order", action="store_true", help="rbp_solver_opts.qp_block_order = 0 (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-mission latency leg (profiling runs: keeps the kernel list clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of the launcher)")
@@ -325,7 +331,9 @@ def main():
     mission, worlds, plans = build_inputs(map_ids, args.agents, param)
     K, N = len(plans), mission.qn
     Ms = sorted({p.M for p in plans})
-    sess = planner.Session(worlds, [mission] * K, param, plans, device=local_rank)
+    opts = planner.solver_opts(qp_schedule={"auto": 0, "mono": 1, "phase": 2}[args.qp_schedule], qp_groups=args.qp_groups,
+                               qp_variant={"auto": 0, "w2": 2, "w4": 4}[args.qp_variant], qp_block_order=0 if args.plain_order else 1)
+    sess = planner.Session(worlds, [mission] * K, param, plans, device=local_rank, opts=opts)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -343,7 +351,7 @@ def main():
         step()
     torch.cuda.synchronize()
     status = sess.download(stream)
-    variant = os.environ.get("RBP_QP_VARIANT", "auto")
+    variant = args.qp_variant if args.qp_schedule != "phase" else "phase"  # (what kernel_source_sha ties a PMC file to)
     if any(status):
         raise SystemExit(f"rank {rank}: missions failed with status {[x for x in status if x][:8]}")
     if dist is not None:
@@ -393,7 +401,7 @@ def main():
         except Exception:
             pass
         sfc_bytes = 4.0 * ct["sfc_samples"]
-        joint_wide = args.joint and (N >= 16 or os.environ.get("RBP_JOINT_WIDE") == "1") and os.environ.get("RBP_JOINT_WIDE", "1") != "0"
+        joint_wide = args.joint and N >= 16  # (rbp_solver_opts.joint_wide_min_agents, default)
         out = {
             "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": value, "unit": "agent-trajectories/s",
             "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * secs / args.steps,
@@ -406,7 +414,8 @@ def main():
                                    f"batch_size={args.batch_size} iteration={args.iteration} (plan_rbp_test.launch keys)",
                        "agents": N, "segments": Ms, "missions_per_gpu": K, "parallelism": f"missions sharded over {n_ranks} GPU(s)",
                        "all_missions_ok": not any(status), "qp_kernel_variant": variant, "baseline_config": args.config or "c3",
-                       "block_order": ("plain (RBP_QP_ORDER=0)" if os.environ.get("RBP_QP_ORDER", "1")[:1] == "0" else
+                       "qp_schedule": args.qp_schedule,
+                       "block_order": ("plain (rbp_solver_opts.qp_block_order = 0)" if args.plain_order else
                                        "longest mission of the session's previous run first (the warm-up steps supply the history; the first "
                                        "run of a session uses plain order; results do not depend on the order)")},
             "value_first_run": K * N / first_run_s,

@@ -102,3 +102,36 @@ def test_abi_version_and_struct_sizes_match_the_binding():
     assert L.rbp_sizeof(99) == 0
     assert b"0.3" in L.rbp_version()
     L.rbp_release_thread_context()   # nothing to release: must be harmless without a device
+
+
+def test_the_library_reads_no_environment_variables():
+    """what a caller may choose about the solvers travels in rbp_solver_opts (include/rbp.h, ABI 4); the release library never calls
+    getenv (the developer build of kernels/jqp.hip does, behind RBP_DEV_KNOBS: `make dev`)"""
+    base = os.path.join(A.REPO_ROOT, "swarm_simulator_amd", "csrc")
+    for root, _, files in os.walk(base):
+        if os.sep + "lib" in root:
+            continue
+        for f in files:
+            if not f.endswith((".hip", ".inc", ".cpp", ".h", ".hpp")):
+                continue
+            text = open(os.path.join(root, f), errors="ignore").read()
+            # strip the developer block
+            text = re.sub(r"#ifdef RBP_DEV_KNOBS.*?#endif", "", text, flags=re.S)
+            code = "\n".join(l.split("//")[0] for l in text.splitlines())
+            assert "getenv" not in code, f
+    import subprocess
+    so = os.path.join(A.LIB_DIR, "librbp_hip.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    assert "getenv" not in syms.split(), "librbp_hip.so imports getenv"
+
+
+def test_solver_opts_defaults_and_checks():
+    o = planner.solver_opts()
+    assert o.size == C.sizeof(A.rbp_solver_opts) == planner.lib().rbp_sizeof(6)
+    assert (o.polish, o.joint_wide_min_agents, o.joint_corrector, o.joint_schedule) == (1, 16, 1, 0)
+    assert (o.qp_schedule, o.qp_variant, o.qp_block_order, o.qp_groups, o.qp_rounds) == (0, 0, 1, 0, 0)
+    bad = planner.solver_opts()
+    bad.size = 8
+    assert planner.lib().rbp_session_set_solver_opts(None, C.byref(bad)) == A.RBP_ERR_BAD_ARGUMENT   # (null session)
+    with pytest.raises(TypeError):
+        planner.solver_opts(no_such_field=1)

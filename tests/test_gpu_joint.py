@@ -6,6 +6,9 @@ Needs an MI355X.
 * 32 / 64 agents: against the committed oracle vectors tests/golden/joint32_map{7,21}.npz / joint64_map{3,12,30}.npz (the oracle needs 26 s / 300 s
   on one core: tests/golden/make_joint_golden.py); 64 agents additionally certified by the independent numpy restatement on a sub-block
   of the QP (rows and variables of eight agents, everything else fixed at the answer);
+* ALL 50 maps of the reference's sweep at 64 and at 32 agents, and a HELD-OUT set no solver constant was ever tuned on (two other
+  64-agent missions and another 32-agent mission on ten maps each, the ICRA world): every mission polished, within CTRL_TOL of the
+  oracle's certified optimum (tests/golden/joint64_sweep.npz, joint32_sweep.npz, joint_heldout.npz);
 * 256 agents (BASELINE config C4's mission, joint): solved, every constraint set of the reference satisfied;
 * sessions: several joint missions in one session == the one-mission calls bit for bit; a second run of a session repeats the first.
 """
@@ -25,6 +28,10 @@ pytestmark = pytest.mark.gpu
 
 CTRL_TOL = 2e-6
 FEAS_TOL = 1e-8
+# the whole-sweep / held-out tests: BASELINE.md 3 "parity gate: feasibility <= 1e-7" (CPLEX's own default is 1e-6).  The joint polish accepts
+# a row violated by up to 5e-8 m after its last refinement round where active rows are nearly dependent (kernels/jqp_polish.inc jp_check);
+# measured: one row of one map (map45, 2.5e-8 m), everything else below 1e-11
+FEAS_TOL_SWEEP = 1e-7
 EQ_TOL = 5e-8
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -52,24 +59,26 @@ def _certify_sub_blocks(p, m, w, init, g, blocks, block=8):
                           pr0.rsfc_time, g.ctrl, True, block, (m.qn + block - 1) // block, only_batches=blocks, ctrl_before_pass=g.ctrl)
 
 
-def _plan(p, m, w, init, wide, monkeypatch):
-    monkeypatch.setenv("RBP_JOINT_WIDE", "1" if wide else "0")
+def _plan(p, m, w, init, wide, **opts):
+    """one mission through the two stage calls; wide: the grid-wide solver (rbp_solver_opts.joint_wide_min_agents = 2) / one workgroup (0)"""
+    ctx = planner.Context(opts=planner.solver_opts(joint_wide_min_agents=2 if wide else 0, **opts))
     g = init.clone_inputs()
-    assert planner.Corridor(w, m, p).update(False, g)
-    pl = planner.RBPPlanner(m, p)
+    assert planner.Corridor(w, m, p, ctx).update(False, g)
+    pl = planner.RBPPlanner(m, p, ctx)
     assert pl.update(False, g), pl.last_error
+    ctx.close()
     return g
 
 
 @pytest.mark.parametrize("n,map_id", [(8, 5), (16, 3)])
-def test_grid_wide_vs_one_workgroup_vs_oracle(n, map_id, monkeypatch):
+def test_grid_wide_vs_one_workgroup_vs_oracle(n, map_id):
     p, m, w, init = _inputs(n, map_id)
     ref = init.clone_inputs()
     assert O.corridor_update(w, m, p, ref)[0] == 0
     rc, rep = O.planner_update(m, p, ref)
     assert rc == 0 and rep["n_polished"] == 1
-    wide = _plan(p, m, w, init, True, monkeypatch)
-    one = _plan(p, m, w, init, False, monkeypatch)
+    wide = _plan(p, m, w, init, True)
+    one = _plan(p, m, w, init, False)
     assert wide.qp_solves == 1 and wide.qp_unpolished == 0 and wide.kkt_max < 1e-9
     for g in (wide, one):
         assert np.abs(ref.ctrl - g.ctrl).max() < CTRL_TOL
@@ -80,11 +89,11 @@ def test_grid_wide_vs_one_workgroup_vs_oracle(n, map_id, monkeypatch):
 
 
 @pytest.mark.parametrize("n,map_id", [(32, 7), (32, 21), (64, 3), (64, 12), (64, 30)])
-def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
+def test_grid_wide_vs_committed_oracle_vector(n, map_id):
     gold = np.load(os.path.join(GOLDEN, f"joint{n}_map{map_id}.npz"))
     p, m, w, init = _inputs(n, map_id)
     assert hashlib.sha256(np.ascontiguousarray(init.init_traj).tobytes()).hexdigest() == str(gold["init_traj_sha256"])
-    g = _plan(p, m, w, init, True, monkeypatch)
+    g = _plan(p, m, w, init, True)
     assert g.M == int(gold["M"]) and g.qp_solves == 1
     assert g.qp_unpolished == 0 and g.kkt_max < 1e-9
     assert np.abs(gold["ctrl"] - g.ctrl).max() < CTRL_TOL
@@ -99,13 +108,13 @@ def test_grid_wide_vs_committed_oracle_vector(n, map_id, monkeypatch):
 
 
 @pytest.mark.parametrize("map_id", [41, 44])
-def test_joint_64_maps_that_lose_the_dual_residual(map_id, monkeypatch):
+def test_joint_64_maps_that_lose_the_dual_residual(map_id):
     """maps 41 and 44 of the sweep: past mu ~ 1e-8 one interior-point step costs the dual residual five orders of magnitude (explicit
     inverses at Newton weights of 1e9) and, depending on last-bit differences of the build, the method then crawled for a hundred
     iterations or ran out of rounds.  The safeguard of jq_ctrl(1) takes that step back and answers with the iterate before it: the
     mission is solved within a normal iteration count, feasible, with a small reported KKT residual (polished or not)."""
     p, m, w, init = _inputs(64, map_id)
-    g = _plan(p, m, w, init, True, monkeypatch)
+    g = _plan(p, m, w, init, True)
     assert g.qp_solves == 1 and g.qp_iterations <= 60
     assert g.kkt_max < 2e-7
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
@@ -113,22 +122,19 @@ def test_joint_64_maps_that_lose_the_dual_residual(map_id, monkeypatch):
     assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
 
 
-def test_joint_centrality_corrector_saves_iterations(monkeypatch):
-    """one Gondzio corrector per iteration (on by default; RBP_JQ_GONDZIO=0 switches it off): fewer iterations, the same optimum"""
+def test_joint_centrality_corrector_saves_iterations():
+    """one Gondzio corrector per iteration (on by default; rbp_solver_opts.joint_corrector = 0 switches it off): fewer iterations, the same optimum"""
     p, m, w, init = _inputs(64, 3)
-    monkeypatch.setenv("RBP_JQ_GONDZIO", "0")
-    plain = _plan(p, m, w, init, True, monkeypatch)
-    monkeypatch.setenv("RBP_JQ_GONDZIO", "1")
-    corr = _plan(p, m, w, init, True, monkeypatch)
+    plain = _plan(p, m, w, init, True, joint_corrector=0)
+    corr = _plan(p, m, w, init, True, joint_corrector=1)
     assert corr.qp_iterations < plain.qp_iterations
     assert corr.qp_unpolished == 0 and plain.qp_unpolished == 0
     assert np.abs(corr.ctrl - plain.ctrl).max() < CTRL_TOL
 
 
-def test_joint_256_agents_solved_and_feasible(monkeypatch):
+def test_joint_256_agents_solved_and_feasible():
     """BASELINE config C4's mission as ONE joint QP: knot blocks of order 2304 (no mission file of this size exists upstream:
     tools/make_mission_256.py).  No oracle can follow (dense LU of order ~1e5): the reference's constraint sets judge the answer."""
-    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
     p = Param.test_sweep(sequential=False, world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5)
     m = host.load_mission("mission_256agents_c4.json")
     w = host.load_world("map1.bt", p)
@@ -137,44 +143,34 @@ def test_joint_256_agents_solved_and_feasible(monkeypatch):
     assert planner.Corridor(w, m, p).update(False, g)
     pl = planner.RBPPlanner(m, p)
     assert pl.update(False, g), pl.last_error
-    assert g.qp_solves == 1 and (g.qp_unpolished == 0 or g.kkt_max < 1e-7)
+    assert g.qp_solves == 1 and g.qp_unpolished == 0 and g.kkt_max < 1e-7
     obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
     assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL
     assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
-    # the numpy restatement on two sub-blocks of eight agents.  The 256-agent answer is usually NOT polished (qp_unpolished = 1: the
-    # active-set polish of kernels/jqp_polish.inc is refused on most problems of this size), i.e. it is an interior-point answer with the
-    # reported KKT residual.  Such a point is not a vertex of its active set, so the certificate's active-set reconstruction (x_as,
-    # forward_error) does not apply; what it certifies then are the KKT residuals of the point itself in the reference's variables:
-    # feasibility, stationarity with multipliers >= 0 (NNLS), complementarity
+    # the numpy restatement on two sub-blocks of eight agents: block-coordinate optimality of the polished answer
     for rep in _certify_sub_blocks(p, m, w, init, g, [5, 20]):
         tag = ", ".join(f"{k}={v:.3g}" for k, v in rep.items() if isinstance(v, float))
-        assert rep["viol_ineq"] < 1e-8 and rep["viol_eq"] < 1e-8, tag
-        if g.qp_unpolished == 0:
-            assert rep["x_as_viol_ineq"] < 1e-7 and rep["stationarity"] < 1e-7 and rep["forward_error"] < CTRL_TOL, tag
-        else:
-            assert rep["stationarity"] < 1e-5 and rep["complementarity"] < 1e-8, tag
+        assert rep["viol_ineq"] < 1e-7 and rep["viol_eq"] < 1e-8, tag
+        assert rep["x_as_viol_ineq"] < 1e-7 and rep["stationarity"] < 1e-7 and rep["forward_error"] < CTRL_TOL, tag
 
 
-def test_joint_schedules_of_the_tile_sweep_agree(monkeypatch):
+def test_joint_schedules_of_the_tile_sweep_agree():
     """look-ahead (default for fewer than eight resident missions) and bulk schedule (jq_update_bulk + a pivot launch per step) of the tile
     sweep on the same mission: the same optimum (both polished, control points within CTRL_TOL; the update kernels accumulate in the same
     order, so in practice the same bits)"""
     p, m, w, init = _inputs(64, 7)
-    monkeypatch.setenv("RBP_JQ_SCHED", "look")
-    look = _plan(p, m, w, init, True, monkeypatch)
-    monkeypatch.setenv("RBP_JQ_SCHED", "bulk")
-    bulk = _plan(p, m, w, init, True, monkeypatch)
+    look = _plan(p, m, w, init, True, joint_schedule=1)
+    bulk = _plan(p, m, w, init, True, joint_schedule=2)
     assert look.qp_unpolished == 0 and bulk.qp_unpolished == 0
     assert look.qp_iterations == bulk.qp_iterations
     assert np.abs(look.ctrl - bulk.ctrl).max() < CTRL_TOL
     assert abs(look.total_cost - bulk.total_cost) <= 1e-10 * max(1.0, look.total_cost)
 
 
-def test_joint_64_session_of_six_maps_is_polished(monkeypatch):
+def test_joint_64_session_of_six_maps_is_polished():
     """six 64-agent joint missions in one session (maps 1..6): every one ends as the KKT-certified optimum of the active-set polish.  Before
     the polish knew about TWINS (the same reduced constraint written twice: last control point of a segment = first of the next under a
     shared box face; jp_twin in kernels/jqp_polish.inc) two of these six were refused."""
-    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
     p = Param.test_sweep(sequential=False)
     m = host.load_mission("mission_64agents_15.json")
     worlds = [host.load_world(f"map{i}.bt", p) for i in range(1, 7)]
@@ -190,47 +186,64 @@ def test_joint_64_session_of_six_maps_is_polished(monkeypatch):
         assert abs(obj - g.total_cost) <= 1e-9 * max(1.0, obj)
 
 
-def test_joint_64_whole_sweep_against_the_oracle(monkeypatch):
-    """all 50 maps of the reference's sweep as 64-agent joint QPs in ONE session, against the oracle's committed answers
-    (tests/golden/joint64_sweep.npz: objective of every map and the control points of agents 0, 21, 42, 63; the oracle needs 5.5 min per map,
-    tests/golden/make_joint_sweep_golden.py).  Where the polish was accepted the GPU's control points are within CTRL_TOL of the oracle's
-    certified optimum and the objectives agree to 1e-8; where it was refused the answer is the interior-point iterate with its reported
-    residual: feasible, objective within 1e-4 relative.  At least 40 of the 50 maps must be polished (49 when this was written)."""
-    path = os.path.join(GOLDEN, "joint64_sweep.npz")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/joint64_sweep.npz not generated (40 min of oracle time: tests/golden/make_joint_sweep_golden.py)")
-    gold = np.load(path)
-    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+def _golden_cases(name):
+    gold = np.load(os.path.join(GOLDEN, name))
+    n = len(gold["cost"])
+    if "mission" in gold.files:
+        cases = [(str(gold["mission"][i]), str(gold["world"][i])) for i in range(n)]
+    else:  # (joint64_sweep.npz, round 4: the 64-agent mission on map1..50, agents 0, 21, 42, 63)
+        cases = [("mission_64agents_15.json", f"map{i + 1}.bt") for i in range(n)]
+    return gold, cases
+
+
+@pytest.mark.parametrize("name", ["joint64_sweep.npz", "joint32_sweep.npz", "joint_heldout.npz"])
+def test_joint_every_mission_ends_at_the_oracles_optimum(name):
+    """Every joint QP ends as the KKT-certified optimum of the active-set polish, within CTRL_TOL of the oracle's certified optimum (control
+    points of four agents of every mission, objective to 1e-8) -- no looser branch for refused polishes: there are none.
+      joint64_sweep.npz   all 50 maps of the reference's sweep, 64 agents (tests/golden/make_joint_sweep_golden.py)
+      joint32_sweep.npz   the same at 32 agents                              (tests/golden/make_joint_heldout_golden.py)
+      joint_heldout.npz   HELD OUT: mission_64agents_12 / _20 / mission_32agents_12 on ten maps each and the 64-agent mission on
+                          ICRA2020_64agents_presentation.bt -- inputs no constant of kernels/jqp*.hip was ever tuned on (two of these
+                          cases were refused when the set was first run; what they showed -- the exchange trusting a dual model that
+                          disagreed with the measured slack of an inactive row -- was fixed in the algorithm, not in a constant).
+    Ten missions of the 64-agent sweep are additionally certified on one sub-block of eight agents each by the independent numpy
+    restatement (block-coordinate optimality with the other 56 agents frozen at the answer)."""
+    gold, cases = _golden_cases(name)
     p = Param.test_sweep(sequential=False)
-    m = host.load_mission("mission_64agents_15.json")
-    worlds = [host.load_world(f"map{i}.bt", p) for i in range(1, 51)]
-    inits = [host.ecbs_plan(w, m, p) for w in worlds]
-    for i, init in enumerate(inits):
-        assert hashlib.sha256(np.ascontiguousarray(init.init_traj).tobytes()).hexdigest() == str(gold["init_traj_sha256"][i]), f"map{i + 1}"
-    plans = [g.clone_inputs() for g in inits]
-    sess = planner.Session(worlds, [m] * 50, p, plans)
-    sess.run(A.RBP_STAGE_ALL)
-    assert sess.download() == [0] * 50
-    sess.close()
-    agents = [int(a) for a in gold["agents"]]
-    n_pol = 0
-    for i, g in enumerate(plans):
-        assert int(gold["rc"][i]) == 0 and g.M == int(gold["M"][i]), f"map{i + 1}"
-        ref_ctrl = gold["ctrl"][i][:, :, :6 * g.M]
-        err = np.abs(ref_ctrl - g.ctrl[agents]).max()
-        rel = abs(float(gold["cost"][i]) - g.total_cost) / max(1.0, abs(g.total_cost))
-        obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
-        assert veq < EQ_TOL and vbox < FEAS_TOL and vrs < FEAS_TOL, f"map{i + 1}"
-        if g.qp_unpolished == 0 and int(gold["polished"][i]) == 1:
-            n_pol += 1
-            assert err < CTRL_TOL and rel < 1e-8, f"map{i + 1}: ctrl {err:.3g} cost {rel:.3g}"
-        else:
-            assert rel < 1e-4 and g.kkt_max < 2e-7, f"map{i + 1}: unpolished, cost {rel:.3g} kkt {g.kkt_max:.3g}"
-    assert n_pol >= 40, n_pol
+    by_n = {}
+    for i, (mf, wf) in enumerate(cases):
+        assert int(gold["rc"][i]) == 0 and int(gold["polished"][i]) == 1, cases[i]
+        by_n.setdefault(int(mf.split("_")[1].replace("agents", "")), []).append(i)
+    for N, idx in sorted(by_n.items()):
+        missions = [host.load_mission(cases[i][0]) for i in idx]
+        worlds = [host.load_world(cases[i][1], p) for i in idx]
+        inits = [host.ecbs_plan(w, m, p) for w, m in zip(worlds, missions)]
+        for k, i in enumerate(idx):
+            assert hashlib.sha256(np.ascontiguousarray(inits[k].init_traj).tobytes()).hexdigest() == str(gold["init_traj_sha256"][i]), cases[i]
+        plans = [g.clone_inputs() for g in inits]
+        sess = planner.Session(worlds, missions, p, plans)
+        sess.run(A.RBP_STAGE_ALL)
+        assert sess.download() == [0] * len(idx)
+        sess.close()
+        agents = [int(a) for a in gold["agents"]] if "agents" in gold.files else [0, N // 3, (2 * N) // 3, N - 1]
+        for k, i in enumerate(idx):
+            g, m = plans[k], missions[k]
+            assert g.M == int(gold["M"][i]) and g.qp_solves == 1, cases[i]
+            assert g.qp_unpolished == 0 and g.kkt_max < 1e-7, f"{cases[i]}: unpolished {g.qp_unpolished} kkt {g.kkt_max:.3g}"
+            err = np.abs(gold["ctrl"][i][:, :, :6 * g.M] - g.ctrl[agents]).max()
+            rel = abs(float(gold["cost"][i]) - g.total_cost) / max(1.0, abs(g.total_cost))
+            assert err < CTRL_TOL and rel < 1e-8, f"{cases[i]}: ctrl {err:.3g} cost {rel:.3g}"
+            obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+            assert veq < EQ_TOL and vbox < FEAS_TOL_SWEEP and vrs < FEAS_TOL_SWEEP, f"{cases[i]}: {veq:.3g} {vbox:.3g} {vrs:.3g}"
+        if name == "joint64_sweep.npz":
+            for k in range(0, len(idx), 5):  # maps 1, 6, ..., 46: one sub-block of eight agents each
+                for rep in _certify_sub_blocks(p, missions[k], worlds[k], inits[k], plans[k], [(k // 5) % 8]):
+                    tag = f"{cases[idx[k]]} agents {8 * rep['batch']}..: " + ", ".join(f"{a}={v:.3g}" for a, v in rep.items() if isinstance(v, float))
+                    assert rep["x_as_viol_ineq"] < 1e-7 and rep["x_as_viol_eq"] < 1e-8 and rep["stationarity"] < 1e-7, tag
+                    assert rep["forward_error"] < CTRL_TOL, tag
 
 
-def test_joint_session_matches_one_mission_calls_and_repeats(monkeypatch):
-    monkeypatch.setenv("RBP_JOINT_WIDE", "1")
+def test_joint_session_matches_one_mission_calls_and_repeats():
     p = Param.test_sweep(sequential=False)
     m = host.load_mission("mission_16agents_15.json")
     maps = [3, 9, 4]  # (M = 34, 34, 36 on these maps: a ragged session)

@@ -1,5 +1,5 @@
 """Developer tool (GPU): copies of the same missions inside one session must agree bit for bit in the control points.
-usage: K=300 REPS=2 [RBP_QP_VARIANT=w2|w4] python tools/determinism_ctrl.py"""
+usage: K=300 REPS=2 [QP_VARIANT=2|4] python tools/determinism_ctrl.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from swarm_simulator_amd.types import Param
 K = int(os.environ.get("K", "300")); REPS = int(os.environ.get("REPS", "2"))
 p = Param.test_sweep(batch_iter=int(os.environ.get("BITER", "-1")))
 m, worlds, plans = bench.build_inputs(bench.shard_missions(K, 0, 1), 64, p)
-s = planner.Session(worlds, [m] * K, p, plans)
+s = planner.Session(worlds, [m] * K, p, plans, opts=planner.solver_opts(qp_variant=int(os.environ.get("QP_VARIANT", "0"))))
 first = None
 for rep in range(REPS):
     s.reset(); s.run(); st = s.download()

@@ -21,7 +21,7 @@ for i in ids:
         cache[i] = (w_, host.ecbs_plan(w_, m, p))
 worlds = [cache[i][0] for i in ids]
 plans = [cache[i][1].clone_inputs() for i in ids]
-sess = planner.Session(worlds, [m] * count, p, plans)
+sess = planner.Session(worlds, [m] * count, p, plans, opts=planner.solver_opts(joint_schedule=int(os.environ.get("JOINT_SCHEDULE", "0"))))
 for rep in range(int(os.environ.get("REPS", "2"))):
     sess.reset()
     t = time.time(); sess.run(A.RBP_STAGE_ALL); st = sess.download(); dt = time.time() - t

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""grid-wide joint QP (kernels/jqp.hip, RBP_JOINT_WIDE=1) vs the one-workgroup joint path and (optionally) the oracle.
+"""grid-wide joint QP (kernels/jqp.hip, rbp_solver_opts.joint_wide_min_agents) vs the one-workgroup joint path and (optionally) the oracle.
 usage: tools/gpu_joint_wide.py [n_agents] [map_id] [--oracle] [--no-wg] [--reps R]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,8 +24,8 @@ base = init.clone_inputs()
 assert planner.Corridor(w, m, p).update(False, base)
 res = {}
 for mode in (["1"] if "--no-wg" in sys.argv else ["1", "0"]):
-    os.environ["RBP_JOINT_WIDE"] = mode
-    pl = planner.RBPPlanner(m, p)
+    ctx = planner.Context(opts=planner.solver_opts(joint_wide_min_agents=2 if mode == "1" else 0, joint_schedule=int(os.environ.get("JOINT_SCHEDULE", "0"))))
+    pl = planner.RBPPlanner(m, p, ctx)
     for rep in range(reps):
         g = base.clone()
         t = time.time(); ok = pl.update(False, g); dt = time.time() - t

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: run the 64-agent joint sweep (maps 1..K, default 50) under several environment settings: "VAR=value VAR2=value2" per argument
+# GPU box (developer library: make -C swarm_simulator_amd/csrc dev; export RBP_HIP_LIB=$PWD/swarm_simulator_amd/lib/librbp_hip_dev.so): the 64-agent joint sweep (maps 1..K, default 50) under several RBP_JQ_* settings: "VAR=value VAR2=value2" per argument
 K=${K:-50}
 for envs in "$@"; do
   echo "== $envs"

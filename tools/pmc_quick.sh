@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): HBM-side bytes per launch of the QP kernel, quick (two PMC passes of a short bench run).
-# usage: tools/pmc_quick.sh [missions-per-gpu]   (env RBP_QP_VARIANT respected)
+# usage: tools/pmc_quick.sh [missions-per-gpu]   (QP_VARIANT=w2|w4 -> bench.py --qp-variant)
 K=${1:-2000}
 OUT=$PWD/gpurun_out/pmcq; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp

@@ -5,8 +5,8 @@ python tools/r05_phase_check.py 12 >> $OUT 2>&1 || { echo "check failed" >> $OUT
 python tools/r05_phase_check.py 1 >> $OUT 2>&1
 python tools/r05_phase_check.py 50 >> $OUT 2>&1
 for cfg in "mono 1" "phase 1" "phase 2" "phase 4" "phase 8"; do set -- $cfg
-  echo "== RBP_QP_PATH=$1 RBP_QP_GROUPS=$2" >> $OUT
-  RBP_QP_PATH=$1 RBP_QP_GROUPS=$2 timeout 600 python bench.py --no-cpu-baseline --no-latency --steps 3 2>&1 | tail -1 | \
+  echo "== --qp-schedule $1 --qp-groups $2" >> $OUT
+  timeout 600 python bench.py --qp-schedule $1 --qp-groups $2 --no-cpu-baseline --no-latency --steps 3 2>&1 | tail -1 | \
     grep -o "\"value\": [0-9.]*\|\"value_first_run\": [0-9.]*\|ipm_iterations_per_step\": [0-9.]*\|unpolished_per_step\": [0-9]*\|\"corridor\": [0-9.]*\|\"planner\": [0-9.]*" | tr "\n" " " >> $OUT; echo >> $OUT
 done
 tail -40 $OUT

@@ -1,5 +1,5 @@
-"""Developer tool (GPU box): the phase-split schedule of the batch QPs (kernels/qp_phase.inc, RBP_QP_PATH=phase) against one workgroup
-per mission (RBP_QP_PATH=mono) on the same missions: status, polish counts, control points, cost, iterations; then wall time of both at
+"""Developer tool (GPU box): the phase-split schedule of the batch QPs (kernels/qp_phase.inc, rbp_solver_opts.qp_schedule = 2) against one workgroup
+per mission (qp_schedule = 1) on the same missions: status, polish counts, control points, cost, iterations; then wall time of both at
 K resident missions.   usage: python tools/r05_phase_check.py [K] [agents] [batch] [iteration]"""
 import os, sys, time
 import numpy as np
@@ -26,9 +26,8 @@ for k in range(K):
 stream = torch.cuda.current_stream().cuda_stream
 res = {}
 for path in ("mono", "phase"):
-    os.environ["RBP_QP_PATH"] = path
     plans = [g.clone_inputs() for g in inits]
-    sess = planner.Session(worlds, [m] * K, p, plans)
+    sess = planner.Session(worlds, [m] * K, p, plans, opts=planner.solver_opts(qp_schedule=2 if path == "phase" else 1, qp_groups=int(os.environ.get("QP_GROUPS", "0"))))
     sess.run(A.RBP_STAGE_ALL, stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

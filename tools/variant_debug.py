@@ -1,4 +1,4 @@
-"""Developer tool: one mission through both builds of the QP kernel (RBP_QP_VARIANT), solver counters printed."""
+"""Developer tool: one mission through both builds of the QP kernel (rbp_solver_opts.qp_variant), solver counters printed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,8 +10,7 @@ p = Param.test_sweep(); m = host.load_mission(mf); w = host.load_world(f"map{mid
 init = host.ecbs_plan(w, m, p)
 ref = None
 for v in ("w2", "w4"):
-    os.environ["RBP_QP_VARIANT"] = v
-    s = planner.Session([w], [m], p, [init.clone_inputs()]); s.run(); st = s.download(); sc = s.scalars()
+    s = planner.Session([w], [m], p, [init.clone_inputs()], opts=planner.solver_opts(qp_variant=int(v[1]))); s.run(); st = s.download(); sc = s.scalars()
     print(v, "status", st, "qps", sc[0, 3], "polished", sc[0, 4], "iters", sc[0, 2], "diag", sc[0, 7], "cost", sc[0, 1])
     if ref is None: ref = s.plans[0].ctrl.copy()
     else: print("   max |w2 - w4| =", np.abs(ref - s.plans[0].ctrl).max())
