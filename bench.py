@@ -217,6 +217,67 @@ def single_sweep_rate(mission_file_agents, param, steps=3):
             "note": "50 missions resident (map1..50, one workgroup each): one pass of the reference's own sweep"}
 
 
+def joint_leg(agents=64):
+    """The JOINT QP (plan/sequential = false, the reference's code default param.hpp:67; kernels/jqp.hip) under the driver's clock:
+    one 64-agent mission through the two synchronous calls (map1), and one pass of the 50-map sweep resident in a session.  Returns the
+    top-level scalars and the roofline_joint block (bound mfma: flops the solver logs for its tile sweeps and substitutions / planner-stage
+    time from HIP events; the dominant kernel's own rate from the committed rocprofv3 summary, tied to the sources by hash)."""
+    import torch
+    from swarm_simulator_amd import planner
+    from swarm_simulator_amd import _abi as A
+    from swarm_simulator_amd.types import Param
+    p = Param.test_sweep(sequential=False)
+    m, worlds, plans = build_inputs(shard_missions(50, 0, 1), agents, p)
+    ctx = planner.Context()
+    best = 1e30
+    for _ in range(2):
+        pr = plans[0].clone_inputs()
+        t0 = time.perf_counter()
+        ok = planner.Corridor(worlds[0], m, p, ctx).update(False, pr) and planner.RBPPlanner(m, p, ctx).update(False, pr)
+        best = min(best, 1e3 * (time.perf_counter() - t0))
+        if not ok:
+            return {"error": "joint mission failed"}
+    single = {"two_calls_ms": best, "iterations": pr.qp_iterations, "unpolished": pr.qp_unpolished, "kkt_max": pr.kkt_max}
+    ctx.close()
+    sess = planner.Session(worlds, [m] * 50, p, plans)
+    stream = torch.cuda.current_stream().cuda_stream
+    sess.run(A.RBP_STAGE_ALL, stream)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    sess.reset(stream)
+    t0 = time.perf_counter()
+    ev[0].record(); sess.run(A.RBP_STAGE_CORRIDOR, stream); ev[1].record(); sess.run(A.RBP_STAGE_PLANNER, stream); ev[2].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    planner_ms = ev[1].elapsed_time(ev[2])
+    ct = sess.counters(stream)
+    status = sess.download(stream)
+    ws = sess.workspace_bytes_per_mission()
+    sess.close()
+    tflops = ct["qp_flops"] / (planner_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "jq_update(_bulk) + jq_panel (joint QP, kernels/jqp.hip)", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "flops_per_sweep": ct["qp_flops"],
+            "ipm_iterations_per_sweep": ct["qp_ipm_iters"], "qps_polished": ct["qp_polished"], "kkt_max": ct["kkt_max"],
+            "note": "whole planner stage of 50 resident 64-agent joint missions (sweeps, factorisations, substitutions, polish): a lower bound "
+                    "of the update kernel's own rate, which kernel_profiled carries"}
+    try:
+        jk = json.load(open(os.path.join(ROOT, "profiles", "r05_joint_kernel.json")))
+        base = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(base)):
+            if f.startswith("jqp"):
+                h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
+        if jk["joint_source_sha"] == h.hexdigest()[:16]:
+            roof["kernel_profiled"] = {"kernel": jk["kernel"], "achieved": jk["tflops"], "unit": "TFLOP/s", "frac": jk["frac_of_fp64_mfma_peak"],
+                                       "share_of_logged_flops": jk["share_of_logged_flops_in_this_kernel"], "missions_per_gpu": jk["missions_per_gpu"],
+                                       "source": "profiles/r05_joint_kernel.json"}
+    except Exception:
+        pass
+    return {"joint_single_mission_ms": single["two_calls_ms"], "joint_single_mission": single,
+            "joint_sweep_value": (50 * m.qn / dt) if not any(status) else None, "joint_sweep_ms": 1e3 * dt,
+            "joint_workspace_bytes_per_mission": ws, "roofline_joint": roof}
+
+
 def sweep_phase_rate(K, agents, resident_wgs=512):
     """roofline.sweep_phase_gbs: the streaming part of qp_batch_kernel judged on its own.  A subprocess runs the SAME workload through the
     developer build of the library that carries the in-kernel phase timers (lib/librbp_hip_prof.so, `make prof`; 100 MHz wall clock per
@@ -460,7 +521,7 @@ def main():
             # the dominant kernel's own rate, from the committed rocprofv3 summary of this very command (a constant tied to the joint
             # solver's sources by hash, like traffic_profiled above; tools/collect_joint_profiles.sh + profiles/README.md say how)
             try:
-                jk = json.load(open(os.path.join(ROOT, "profiles", "r04_joint_kernel.json")))
+                jk = json.load(open(os.path.join(ROOT, "profiles", "r05_joint_kernel.json")))
                 base = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
                 h = hashlib.sha256()
                 for f in sorted(os.listdir(base)):
@@ -468,7 +529,7 @@ def main():
                         h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
                 if jk["joint_source_sha"] == h.hexdigest()[:16] and jk["missions_per_gpu"] == K and jk["agents"] == N:
                     out["roofline"]["kernel_profiled"] = {"kernel": jk["kernel"], "achieved": jk["tflops"], "unit": "TFLOP/s",
-                                                          "frac": jk["frac_of_fp64_mfma_peak"], "source": "profiles/r04_joint_kernel.json"}
+                                                          "frac": jk["frac_of_fp64_mfma_peak"], "source": "profiles/r05_joint_kernel.json"}
             except Exception:
                 pass
         # the single-mission latency and the CPU baseline are rank-0, N = 1 legs (the other ranks would only wait for them)
@@ -494,6 +555,10 @@ def main():
                 "note": "algorithmic bytes of the row sweeps (BUILD, AFF, STEP, NBHD, UPDATE) / the time the workgroups spend in those "
                         "phases (in-kernel 100 MHz timers of the profiling build, same workload, separate process), times the workgroups "
                         "resident at a time; the timers add a barrier per phase, so this is a slight under-estimate"}
+            try:  # the joint QP (plan/sequential = false) under the same clock: VERDICT r04 item 3
+                out.update(joint_leg(args.agents))
+            except Exception as e:
+                out["roofline_joint"] = {"error": str(e)}
             out["single_mission_two_calls_ms"] = lat.get("two_calls_ms") if isinstance(lat, dict) else None
             out["single_sweep_value"] = ss.get("value") if isinstance(ss, dict) else None
         if world_size == 1 and not args.no_cpu_baseline:

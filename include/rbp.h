@@ -230,6 +230,9 @@ typedef struct rbp_counters {
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 
+/* bytes of QP workspace one mission of this session occupies (0 until the first PLANNER run has reserved it) */
+size_t rbp_session_workspace_bytes(rbp_session* s);
+
 /* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 28 = SC_N (layout: kernels/rbp_dev.h SC_*) */
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
 

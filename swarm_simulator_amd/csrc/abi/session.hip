@@ -282,6 +282,17 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
         const size_t words = ((((nc + 63) >> 6) * 2 + 2) + 3) & ~size_t(3);
         if (words <= SFC_MASK_WORDS) d.sfc_mask_words = std::max(d.sfc_mask_words, (int)words);
     }
+    {   // sfc_kernel keeps box_log [max_boxes][M + 1] per agent of a workgroup in LDS, beside the mask and the key lists: refuse here, with the
+        // numbers, what the launch would refuse with a generic HIP error (the QP kernels take M <= QP_MAX_M = 128; the corridor's
+        // bound depends on max_boxes, which defaults to M)
+        int lds_max = 160 * 1024;
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+        const size_t need = corridor_lds_bytes(d);
+        if (need > (size_t)std::max(lds_max, 64 * 1024))
+            return fail(RBP_ERR_BAD_ARGUMENT, "Corridor: " + std::to_string(need) + " bytes of LDS per workgroup for max_boxes = " + std::to_string(MB) +
+                                                  ", M = " + std::to_string(M) + " (box_log is [max_boxes][M + 1] per agent) exceed the device's " +
+                                                  std::to_string(lds_max) + "; pass a smaller plan.max_boxes (the reference's corridors hold ~6-10 boxes per agent)");
+    }
     for (int a = 0; a < 3; ++a) d.p.world_min[a] = param->world_min[a], d.p.world_max[a] = param->world_max[a];
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
@@ -477,6 +488,8 @@ static int ensure_planner_workspace(rbp_session* s, hipStream_t st) {
     return RBP_OK;
 }
 
+size_t rbp_session_workspace_bytes(rbp_session* s) { return s && s->qp_ws ? s->qp_ws_per_mission : 0; }
+
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     int rc = check_solver_opts(o);
@@ -496,7 +509,10 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     }
     s->last_stages = stages;
     s->d.p.polish = o.polish ? 1 : 0;
-    if (stages & RBP_STAGE_CORRIDOR) launch_corridor(s->d, st);
+    if (stages & RBP_STAGE_CORRIDOR) {
+        int rc = launch_corridor(s->d, st);
+        if (rc) return rc;
+    }
     if ((stages & RBP_STAGE_PLANNER) && s->joint_wide) {
         // grid-wide joint QP: a launch per phase; the host learns once per interior-point iteration whether any mission is still
         // running, so this call SYNCHRONISES the stream (unlike the batch path, which only enqueues)

@@ -591,16 +591,24 @@ __global__ __launch_bounds__(256) void rsfc_kernel(DevSession s) {
 
 }  // namespace
 
-void launch_corridor(const DevSession& s, hipStream_t st) {
+// dynamic LDS of sfc_kernel: occupancy mask + per wave the key lists and box_log [max_boxes][M + 1] (checked against the CU's LDS when a
+// session is created: abi/session.hip)
+size_t corridor_lds_bytes(const DevSession& s) {
+    const int kw = (s.sfc_cap[0] + s.sfc_cap[1] + s.sfc_cap[2] + 3 * SFC_SLAB + 1) & ~1;
+    return sizeof(unsigned) * s.sfc_mask_words + sizeof(sfc_key_t) * (size_t)SFC_WAVES * kw +
+           sizeof(sfc_log_t) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1) + 16;
+}
+
+int launch_corridor(const DevSession& s, hipStream_t st) {
     // updateObsBox() && updateRelBox() (:25): RSFC results are only meaningful if SFC succeeded; status keeps the
     // first error, with SFC errors taking precedence because sfc_kernel is enqueued first.
-    const int kw = (s.sfc_cap[0] + s.sfc_cap[1] + s.sfc_cap[2] + 3 * SFC_SLAB + 1) & ~1;
-    const size_t lds = sizeof(unsigned) * s.sfc_mask_words + sizeof(sfc_key_t) * (size_t)SFC_WAVES * kw +
-                       sizeof(sfc_log_t) * (size_t)SFC_WAVES * s.max_boxes * (s.M + 1) + 16;
+    const size_t lds = corridor_lds_bytes(s);
     const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
-    (void)hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return rbp_set_error(RBP_ERR_HIP, "sfc_kernel: the dynamic LDS it needs was refused by the device");
     if (groups > 0) hipLaunchKernelGGL(mask_kernel, dim3(SFC_MASK_BLOCKS, s.K), dim3(256), 0, st, s);
     if (groups > 0) hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
     const long long total = (long long)s.K * s.npair * s.M;
     if (total > 0) hipLaunchKernelGGL(rsfc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s);
+    return RBP_OK;
 }

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void jq_ctrl(JArgs A, int which, int first) {
                 else
                     st[ST_STATE] = 1.0;
             } else if (!(gap == gap) || st[ST_ITER] >= JQ_MAX_ITERS) {
-                st[ST_STATE] = 2.0, st[ST_REASON] = 3.0;  // iteration cap (or NaN)
+                st[ST_STATE] = 2.0, st[ST_REASON] = st[ST_BADPIV] != 0.0 ? 2.0 : 3.0;  // iteration cap or NaN (2: after a non-positive pivot of a knot's Schur complement)
             } else {
                 // early crossover (qp.hip): once the active set shows (A.early_mu: see launch_planner_joint)
                 const int tries = (int)st[ST_TRIES];
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int m
     store_pivot_inverse(Am, c.Pk);
     // a non-positive pivot (the matrix is SPD in exact arithmetic) is counted, not fatal: the sweep needs no square roots, and with
     // Newton weights of 1e9 the last interior-point iterations work at the edge of double precision
-    if (bad && threadIdx.x == 0) *c.bad += 1.0;
+    if (bad && threadIdx.x == 0) *c.bad = 1.0;  // (a flag: the two chains' workgroups may both set it, never a read-modify-write)
 }
 
 // operand fragments of a 16-row block for v_mfma_f64_16x16x4_f64 over K = 64: lane (i, g) holds rows[i][16 ch + 4 g + q], ch, q = 0..3
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         __syncthreads();
         inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
         store_pivot_inverse(Am, c.Pn);
-        if (bad && tid == 0) *c.bad += 1.0;
+        if (bad && tid == 0) *c.bad = 1.0;
     }
 }
 
@@ -1618,8 +1618,18 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     JQ_LAUNCH(jq_sweep<PASS_INIT>, dim3(nsw, K), 0, A);
     JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 0, 0);
     std::vector<double> state((size_t)K);
-    double* state_h = nullptr;
-    if (hipHostMalloc((void**)&state_h, sizeof(double) * K * ST_N) != hipSuccess) return RBP_ERR_HIP;
+    struct Pinned {  // the poll buffer (freed on every exit path)
+        double* p = nullptr;
+        ~Pinned() {
+            if (p) (void)hipHostFree(p);
+        }
+    } pinned;
+    if (hipHostMalloc((void**)&pinned.p, sizeof(double) * K * ST_N) != hipSuccess) return RBP_ERR_HIP;
+    double* state_h = pinned.p;
+    // jq_mv keeps one vector of nkp doubles in dynamic LDS: above the default 64 KB the limit has to be raised, above the CU's 160 KB
+    // (N > 2275 agents) the launch cannot be made at all
+    if ((size_t)dm.nkp * sizeof(double) > 160 * 1024) return RBP_ERR_BAD_ARGUMENT;
+    if (hipFuncSetAttribute((const void*)jq_mv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dm.nkp * sizeof(double))) != hipSuccess) return RBP_ERR_HIP;
     int nref_round = 0;  // refinement steps per solve in this round (the largest any mission asked for; the kernels gate per mission)
     auto substitute = [&](int which_out) {
         for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 0, sidx);
@@ -1847,7 +1857,6 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     }
     JQ_LAUNCH(jq_finish, dim3(K), 0, A);
     if (stats) stats->rounds = iters, stats->polish_rounds = polish_rounds;
-    (void)hipHostFree(state_h);
     if (hipGetLastError() != hipSuccess) rc = RBP_ERR_HIP;
     return rc;
 }

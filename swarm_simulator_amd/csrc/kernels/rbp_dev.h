@@ -86,7 +86,8 @@ enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 int rbp_set_error(int code, const char* msg);  // abi/session.hip: records the message rbp_last_error() returns, returns code
 
 // launchers (defined in the .hip files)
-void launch_corridor(const DevSession& s, hipStream_t st);
+int launch_corridor(const DevSession& s, hipStream_t st);
+size_t corridor_lds_bytes(const DevSession& s);  // dynamic LDS of sfc_kernel for this session's shapes
 // kernels/qp.hip is built twice: _w2 = 256 VGPRs, one workgroup per CU; _w4 = 128 VGPRs, two workgroups per CU
 void launch_planner_w2(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);
 void launch_planner_w4(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st);

@@ -76,12 +76,14 @@ def gather_corridor(dist, plan: PlanResult, n_agents: int, slices, dev="cpu"):
     buf[:mine.size] = mine
     t = torch.from_numpy(buf).to(dev)
     out = torch.empty(world * maxb, dtype=torch.uint8, device=dev)
-    try:
-        dist.all_gather_into_tensor(out, t)          # one collective: RCCL over xGMI on the GPU box
-    except (RuntimeError, NotImplementedError):       # a backend without the flat form
+    # (the path is chosen from the backend, not by catching what the collective throws: a genuine RCCL failure must surface, and ranks
+    # that disagree about a fallback would issue mismatched collectives and hang)
+    if dist.get_backend() == "gloo":   # gloo: the list form (tests)
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         out = torch.cat(outs)
+    else:
+        dist.all_gather_into_tensor(out, t)          # one collective: RCCL over xGMI on the GPU box
     host = out.cpu().numpy()
     for r in range(world):
         if r != rank:
@@ -121,12 +123,12 @@ def gather_corridor_device(dist, arrs, n_agents, slices):
     t = torch.zeros(maxb, dtype=torch.uint8, device=mine.device)
     t[:mine.numel()] = mine
     out = torch.empty(world * maxb, dtype=torch.uint8, device=mine.device)
-    try:
-        dist.all_gather_into_tensor(out, t)          # RCCL: one collective on the device buffers
-    except (RuntimeError, NotImplementedError):       # gloo (tests: two ranks on one GPU) has neither the flat form nor device all_gather
+    if dist.get_backend() == "gloo":   # tests: two ranks on one GPU (RCCL refuses that); gloo has neither the flat form nor device all_gather
         outs = [torch.empty(maxb, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(outs, t.cpu())
         out = torch.cat(outs).to(mine.device)
+    else:
+        dist.all_gather_into_tensor(out, t)          # RCCL: one collective on the device buffers
     for r in range(world):
         if r != rank:
             unpack_shard_device(arrs, out[r * maxb:r * maxb + lens[r]], slices[r], offs[r])
