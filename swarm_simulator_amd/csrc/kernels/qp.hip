@@ -2513,7 +2513,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             __syncthreads();
             PROF(0);
 #ifdef QP_POLSTATS
-            if (tid == 0) scal[20] += 1, scal[21] += (acc == 0), scal[22] += (early_tries == 2), scal[23] += (early_tries == 2 && acc == 0);
+            if (tid == 0 && !polish_first) scal[25] += (early_tries == 1), scal[26] += (early_tries == 1 && acc == 0), scal[27] += (early_tries == 2), scal[29] += (early_tries == 2 && acc == 0);  // (tools/r05_polstats.py)
 #endif
             if (acc == 0) {
                 ok = true, polished = 1;
@@ -2657,6 +2657,9 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             acc = polish_entry(c, pw, lds, red2, flag2, 2);
         }
         polished = acc == 0 ? 1 : 0;
+#ifdef QP_POLSTATS
+        if (tid == 0) scal[30] += 1, scal[31] += polished;
+#endif
         PROF(0);
 #ifndef QP_PROFILE
         if (acc != 0 && tid == 0) scal[SC_PROF0] += 1000.0 * batch + acc;  // diagnostic: which batch was not polished, and why
