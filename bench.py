@@ -40,7 +40,7 @@ CONFIGS = {  # BASELINE.json configs -> flags (C1 is the CPU plumbing case of th
 }
 
 
-PMC_FILE = "profiles/r04_pmc.json"   # HBM-side bytes per launch, collected by tools/collect_profiles.sh on the sources hashed below
+PMC_FILE = "profiles/r05_pmc.json"   # HBM-side bytes per launch, collected by tools/collect_profiles.sh on the sources hashed below
 
 
 def kernel_source_sha(variant="auto"):
