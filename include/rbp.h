@@ -230,8 +230,11 @@ typedef struct rbp_counters {
 } rbp_counters;
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream);
 
-/* bytes of QP workspace one mission of this session occupies (0 until the first PLANNER run has reserved it) */
+/* bytes of QP workspace one mission of this session occupies (0 until it has been reserved) */
 size_t rbp_session_workspace_bytes(rbp_session* s);
+/* reserve (and clear) the QP workspace for the solver options in force now, instead of leaving it to the first PLANNER run: a caller that
+ * times its first plan, or wants the allocation failure before it has uploaded anything else */
+int rbp_session_reserve_workspace(rbp_session* s, void* stream);
 
 /* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 28 = SC_N (layout: kernels/rbp_dev.h SC_*) */
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);

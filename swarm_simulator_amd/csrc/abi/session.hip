@@ -490,6 +490,12 @@ static int ensure_planner_workspace(rbp_session* s, hipStream_t st) {
 
 size_t rbp_session_workspace_bytes(rbp_session* s) { return s && s->qp_ws ? s->qp_ws_per_mission : 0; }
 
+int rbp_session_reserve_workspace(rbp_session* s, void* stream) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    return ensure_planner_workspace(s, (hipStream_t)stream);
+}
+
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     int rc = check_solver_opts(o);

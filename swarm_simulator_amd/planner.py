@@ -108,6 +108,7 @@ def lib():
         L.rbp_solver_opts_defaults.restype = None
         L.rbp_session_set_solver_opts.argtypes = [C.c_void_p, P(A.rbp_solver_opts)]
         L.rbp_ctx_set_solver_opts.argtypes = [C.c_void_p, P(A.rbp_solver_opts)]
+        L.rbp_session_reserve_workspace.argtypes = [C.c_void_p, C.c_void_p]
         L.rbp_session_workspace_bytes.argtypes = [C.c_void_p]
         L.rbp_session_workspace_bytes.restype = C.c_size_t
         L.rbp_ctx_create.argtypes = [P(C.c_void_p), C.c_int]
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "rbp_last_error", "rbp_device_count",
     "rbp_ctx_create", "rbp_ctx_destroy", "rbp_ctx_corridor_update", "rbp_ctx_planner_update", "rbp_ctx_plan_update",
     "rbp_session_create_in",
-    "rbp_solver_opts_defaults", "rbp_session_set_solver_opts", "rbp_ctx_set_solver_opts", "rbp_session_workspace_bytes",
+    "rbp_solver_opts_defaults", "rbp_session_set_solver_opts", "rbp_ctx_set_solver_opts", "rbp_session_workspace_bytes", "rbp_session_reserve_workspace",
     "rbp_edt_dims", "rbp_edt_build",
 ]
 
@@ -294,6 +295,12 @@ class Session:
         for p, c in zip(self.plans, self._pl):
             p.sync_from(c)
         return st.tolist()
+
+    def reserve_workspace(self, stream=None):
+        """reserve the QP workspace now (otherwise the first PLANNER run does)"""
+        rc = lib().rbp_session_reserve_workspace(self._h, C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_reserve_workspace rc={rc}: {last_error()}")
 
     def workspace_bytes_per_mission(self):
         return int(lib().rbp_session_workspace_bytes(self._h))

@@ -4,7 +4,7 @@
 #   * scratch instructions (scratch_load/scratch_store) per FUNCTION from the ISA: the QP kernel is many __noinline__ functions, and a
 #     spill inside a loop costs more than a prologue's.
 # usage: tools/resource_usage.sh r03
-TAG=${1:-r03}; cd "$(dirname "$0")/../swarm_simulator_amd/csrc" || exit 1
+TAG=${1:-r05}; cd "$(dirname "$0")/../swarm_simulator_amd/csrc" || exit 1
 OUT=../../profiles/${TAG}_resource_usage.txt
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include -Ikernels -Iabi --cuda-device-only"
 one() {  # name, source, extra flags
@@ -19,6 +19,7 @@ one() {  # name, source, extra flags
   echo "# compile-time resource usage, $TAG (tools/resource_usage.sh: hipcc -Rpass-analysis=kernel-resource-usage; per-function scratch instruction counts from the ISA)"
   one "build _w2 (-DQP_WAVES_PER_EU=2 -DQP_ROW_PF=4 -DQP_SUFFIX=_w2)" kernels/qp.hip "-DQP_WAVES_PER_EU=2 -DQP_ROW_PF=4 -DQP_SUFFIX=_w2"
   one "build _w4 (-DQP_THREADS=256 -DQP_WAVES_PER_EU=2 -DQP_SUFFIX=_w4)" kernels/qp.hip "-DQP_THREADS=256 -DQP_WAVES_PER_EU=2 -DQP_SUFFIX=_w4"
+  one "(every jq_* / jp_* kernel of the grid-wide joint solver)" kernels/jqp.hip ""
   one "" kernels/corridor.hip ""
   one "" kernels/edt.hip ""
 } > $OUT
