@@ -56,6 +56,16 @@
 #ifndef QP_ROW_PF
 #define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
 #endif
+#ifndef QP_FAR_SLACK
+// REDUCED ROW SET of the interior-point phase (round 5).  A frozen-neighbour row whose slack at the batch QP's starting point exceeds this
+// many metres for all six control points of its (agent, segment) group is FAR: the interior-point sweeps do not walk it (no (s, z), no
+// weight, no ratio test).  Correctness does not depend on the choice: the active-set polish verifies EVERY row of the full QP at the point it
+// proposes (far rows that come out violated join the candidates and the dual is solved again), and a batch QP whose polish is refused -- or
+// whose interior-point method fails -- while far rows exist is solved again from its starting point with every row near.  Applies to the
+// first Gauss-Seidel pass of the sequential schedule with the polish on; 1e300 = off.
+#define QP_FAR_SLACK 0.7  // (A/B on one box, 2000 missions resident: off 100.1 k, 1.0 m 123.2 k, 0.7 m 127.7 k, 0.5 m 127.2 k agent-trajectories/s;
+                          // batch QPs solved twice on the 50-map sweep: 0 / 1 / 8 of 800; 0.25 m costs iterations: profiles/r05_ab_reduced_rows.txt)
+#endif
 #ifndef QP_SIGMA_POW
 #define QP_SIGMA_POW 3  // Mehrotra's centring exponent
 #endif
@@ -188,6 +198,8 @@ struct QpWs {
     double *Lk, *Dk, *Ek;           // [M+1][9]
     double *segsc;                  // [M] dt^-5 (build_Q_p :349-351)
     int *flist, *fcnt, *fbase;      // non-redundant frozen neighbours per (batch agent, segment): [nb][M][NF], [nb][M], [nb][M]
+    int *fnear;                     // (round 5) [nb][M] how many of a group's neighbours are NEAR (they come first in its rows; the far ones sit at
+                                    // the back of its flist): the interior-point sweeps only walk the near rows (see QP_FAR_SLACK)
     int *fperm, *frank;             // [nb][M]: groups ordered by falling row count (fperm[rank] = group, frank[group] = rank)
     int *tile_base;                 // [ntile + 1] first slot of each tile
     int *wi_of;                     // [nb*oq] column (wi) of control point (a, j6)
@@ -198,7 +210,7 @@ struct QpWs {
 
 __host__ __device__ inline size_t ws_int_count(int N, int M, int nbmax) {
     QpDims d = make_dims(N, M, 0, nbmax);
-    return (size_t)nbmax * M * N /*flist*/ + 4 * (size_t)nbmax * M /*fcnt fbase fperm frank*/ + d.ntile + 1 + (size_t)nbmax * d.oq /*wi_of*/ +
+    return (size_t)nbmax * M * N /*flist*/ + 5 * (size_t)nbmax * M /*fcnt fbase fperm frank fnear*/ + d.ntile + 1 + (size_t)nbmax * d.oq /*wi_of*/ +
            3 * (size_t)nbmax * M * N /*nrm (floats)*/ + 8;
 }
 
@@ -251,6 +263,7 @@ __device__ inline QpWs carve(double* base, const QpDims& d, int nbmax) {
     w.segsc = p, p += d.M;
     int* ip = (int*)p;
     w.flist = ip, ip += (size_t)nbmax * d.M * d.N;
+    w.fnear = ip, ip += (size_t)nbmax * d.M;
     w.fcnt = ip, ip += (size_t)nbmax * d.M;
     w.fbase = ip, ip += (size_t)nbmax * d.M;
     w.fperm = ip, ip += (size_t)nbmax * d.M;
@@ -616,7 +629,11 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
         // ---- frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped): a stream
         // over the SELL arrays; the signed normal is shared by the six rows of the group
-        const int cnt = w.fcnt[grp];
+        // PRESOLVE / VERIFY / CAND_GEO see every row; the passes of the interior-point loop the near ones (the near rows come first in a
+        // group's list); CAND walks all of them to clear the far rows' candidate marks
+        constexpr bool all_rows = (PASS == PASS_PRESOLVE || PASS == PASS_VERIFY || PASS == PASS_CAND_GEO || PASS == PASS_CAND);
+        const int cnt_near = w.fnear[grp];
+        const int cnt = all_rows ? w.fcnt[grp] : cnt_near;
         const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
         const size_t r0 = base + (size_t)d.ncol0 * 64;
 #if QP_ROW_PF > 0
@@ -637,6 +654,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
         for (int idx = 0; idx < cnt; ++idx) {
             const size_t r = r0 + (size_t)idx * 64;
+            const bool far_row = PASS == PASS_CAND && idx >= cnt_near;
             const double n0 = pn[0][0], n1 = pn[0][1], n2 = pn[0][2], rhv = ph[0], s_in = ps[0], z_in = pz[0];
 #pragma unroll
             for (int u = 0; u + 1 < QP_ROW_PF; ++u) {
@@ -651,6 +669,10 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
                 ph[QP_ROW_PF - 1] = w.rh[rx];
 #pragma unroll
                 for (int e = 0; e < 3; ++e) pn[QP_ROW_PF - 1][e] = nr[3 * ix + e];
+            }
+            if (far_row) {  // (see the plain loop below)
+                w.cc[r] = 0.0;
+                continue;
             }
             const double slack = rhv - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
             double wgt = 0, v = 0, zo = 0;
@@ -672,6 +694,10 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
 #pragma unroll QP_ROW_UNROLL
         for (int idx = 0; idx < cnt; ++idx) {
             const size_t r = r0 + (size_t)idx * 64;
+            if (PASS == PASS_CAND && idx >= cnt_near) {  // a far row: no (s, z); not a candidate unless a verification finds it violated
+                w.cc[r] = 0.0;
+                continue;
+            }
             const double n0 = nr[3 * idx], n1 = nr[3 * idx + 1], n2 = nr[3 * idx + 2];
             const double slack = w.rh[r] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
             double wgt = 0, v = 0, zo = 0;
@@ -2162,8 +2188,9 @@ __device__ double trc_sum(const double* p, size_t n, double* red) {
 // set-up of one batch QP (all threads of the workgroup): mission constants, the SFC box of every (batch agent, segment), the pinned end
 // control points, the presolve lists and the row constants.  false: the mission was abandoned (S.status set).
 // ------------------------------------------------------------------------------------------------------------
+// far_R: QP_FAR_SLACK of this attempt (1e300: every row near); nfar: how many (group, neighbour) entries were classified far.
 __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, double* ctrl, const double* T, int mission, int first, int nb,
-                                               int* flag, double* lds, int& frozen_free_rows) {
+                                               int* flag, double* lds, int& frozen_free_rows, double far_R, int& nfar) {
     const int tid = threadIdx.x, N = S.N;
     const QpDims& d = c.d;
     const QpWs& w = c.w;
@@ -2236,12 +2263,17 @@ __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, d
         const double ra = c.radius[qa];
         const double* lo = w.boxlo + ((size_t)a * M + seg) * 3;
         const double* hi = w.boxhi + ((size_t)a * M + seg) * 3;
-        int cnt = 0;
+        int cnt = 0, nfar_g = 0;
         int* fl = w.flist + (size_t)it * N;
+        double xa6[6][3];  // this group's own control points at the starting point (the near / far classification, see QP_FAR_SLACK)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) xa6[i][e] = ctrl[((size_t)qa * 3 + e) * d.oq + 6 * seg + i];
         // (four neighbours per round, all their loads ahead of the list stores: the compiler does not move a load across a store, and a
         // neighbour per round meant 60 trips to memory in a row, ~1 us each under load)
         for (int f0 = 0; f0 < N && N > 1; f0 += 4) {
-            bool keep4[4];
+            bool keep4[4], far4[4];
             float nvq[4][3];
             double cf[4][6][3];
 #pragma unroll
@@ -2266,36 +2298,49 @@ __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, d
                 const double mx = fmax(n0 * lo[0], n0 * hi[0]) + fmax(n1 * lo[1], n1 * hi[1]) + fmax(n2 * lo[2], n2 * hi[2]);
                 const double rr = ra + c.radius[f < N ? f : 0];
                 bool keep = false;
+                double smin = 1e300;  // smallest slack of the group's six rows at the starting point
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const double nd = n0 * cf[q][i][0] + n1 * cf[q][i][1] + n2 * cf[q][i][2];
                     if (!(nd - rr - mx > 1e-6)) keep = true;
+                    smin = fmin(smin, nd - rr - (n0 * xa6[i][0] + n1 * xa6[i][1] + n2 * xa6[i][2]));
                 }
                 keep4[q] = keep && f < N && !(f >= first && f < first + nb);
+                far4[q] = smin > far_R;
             }
+            // the near neighbours fill the group's list from the front, the far ones from the back (entry idx >= near count of the group's
+            // rows is fl[N - 1 - (idx - near count)]): the rows of the interior-point phase come first in every column
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (keep4[q]) fl[cnt++] = f0 + q;
+                if (keep4[q]) {
+                    if (far4[q])
+                        fl[N - 1 - nfar_g++] = f0 + q;
+                    else
+                        fl[cnt++] = f0 + q;
+                }
         }
-        w.fcnt[it] = cnt;
+        w.fnear[it] = cnt;
+        w.fcnt[it] = cnt + nfar_g;
     }
     __threadfence_block();
     __syncthreads();
     // offsets of the groups' normal lists (exclusive prefix sum of the counts) and the number of non-constant frozen rows: every group
     // sums its predecessors itself -- loads only, all in flight together; one thread walking the 144 groups with a store per step made
     // 144 trips to memory in a row
-    if (tid == 0) *flag = 0;
+    if (tid == 0) flag[0] = 0, flag[1] = 0;
     __syncthreads();
     for (int it = tid; it < nb * M; it += QP_THREADS) {
         int acc = 0;
         for (int o = 0; o < it; ++o) acc += w.fcnt[o];
         w.fbase[it] = acc;
         const int seg = it % M;
-        atomicAdd(flag, w.fcnt[it] * ((seg == 0 || seg == M - 1) ? (M == 1 ? 0 : 3) : 6));
+        atomicAdd(flag, w.fnear[it] * ((seg == 0 || seg == M - 1) ? (M == 1 ? 0 : 3) : 6));  // (rows of the interior-point phase: the near ones)
+        atomicAdd(flag + 1, w.fcnt[it] - w.fnear[it]);
     }
     __threadfence_block();
     __syncthreads();
     frozen_free_rows = *flag;
+    nfar = flag[1];
     __syncthreads();
     // sweep work order: the threads of a wavefront walk the row lists of their control points in lockstep, so a wave
     // costs as much as its longest list.  Handing out the (agent, segment) groups by falling row count puts lists of
@@ -2329,7 +2374,7 @@ __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, d
     // rh = n . d_f - (r_a + r_f)
     for (int it = tid; it < nb * M * 6; it += QP_THREADS) {
         const int as = it / 6, i = it % 6, a = as / M, seg = as % M, qa = first + a, j6 = 6 * seg + i;
-        const int cnt = w.fcnt[as];
+        const int cnt = w.fcnt[as], cn = w.fnear[as];
         const int* fl = w.flist + (size_t)as * N;
         const int wi = 6 * w.frank[as] + i;
         const size_t r0 = (size_t)w.tile_base[wi >> 6] + (wi & 63) + (size_t)d.ncol0 * 64;
@@ -2340,7 +2385,10 @@ __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, d
             float nvq[4][3];
             double cfq[4][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fq[q] = fl[i0 + q < cnt ? i0 + q : cnt - 1];
+            for (int q = 0; q < 4; ++q) {
+                const int e = i0 + q < cnt ? i0 + q : cnt - 1;
+                fq[q] = fl[e < cn ? e : N - 1 - (e - cn)];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int f = fq[q];
@@ -2369,16 +2417,18 @@ __device__ __forceinline__ bool qp_setup_batch(const DevSession& S, RowCtx& c, d
 // ------------------------------------------------------------------------------------------------------------
 // one batch QP of one mission (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
-                                              int reset_cost, int lds_doubles, int pass_index) {
+// far_R: see QP_FAR_SLACK.  Returns 1 when the batch QP has to be solved again with every row near (the caller puts the batch agents'
+// control points back to the starting point first), else 0.
+__device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
+                                             int reset_cost, int lds_doubles, int pass_index, double far_R) {
     const int tid = threadIdx.x;
-    if (S.status[mission] != 0) return;
+    if (S.status[mission] != 0) return 0;
     // M of this mission: made wave-uniform explicitly (an SGPR like every other dimension; as a per-lane value it was spilled
     // and reloaded under divergent control flow with some lanes reading garbage)
     const int N = S.N, M = __builtin_amdgcn_readfirstlane(S.Mk[mission]), MS = S.M;  // MS: slot stride of the per-mission arrays
     const int first = batch * nbmax;
     const int nb = min(nbmax, N - first);
-    if (nb <= 0) return;
+    if (nb <= 0) return 0;
     RowCtx c;
     c.scal = S.scalars + (size_t)mission * SC_N, c.mission = mission, c.lds_avail = lds_doubles - 32;
     c.d = make_dims(N, M, first, nb);
@@ -2408,8 +2458,8 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
     int* flag2 = flag;
 
     PROF_DECL;
-    int frozen_free_rows = 0;
-    if (!qp_setup_batch(S, c, ctrl, T, mission, first, nb, flag, lds, frozen_free_rows)) return;
+    int frozen_free_rows = 0, nfar = 0;
+    if (!qp_setup_batch(S, c, ctrl, T, mission, first, nb, flag, lds, frozen_free_rows, far_R, nfar)) return 0;
     PROF(8);  // batch setup: constants, SFC boxes, presolve lists, row constants
     PassIO io;
     __shared__ RowCtx c_lds;  // the sweeps' view of the row context (see sweep<>)
@@ -2428,7 +2478,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             scal[SC_PROF0 + 1] = 1000.0 * batch + 1, scal[SC_PROF0 + 2] = pin_viol;  // why: a constant (pinned) row is violated
 #endif
         }
-        return;
+        return 0;
     }
     const double nrows_free = (double)((size_t)(d.oq - 6) * (6 * d.nb + d.npb)) + (double)frozen_free_rows;  // every pair row once
     bool ok = false;
@@ -2640,6 +2690,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         PROF(10);
         PROF(11);
     }
+    if (!ok && nfar > 0) {  // the interior-point method failed on the reduced row set: once more with every row
+        if (tid == 0) scal[SC_IPM_ITERS] += it_count, scal[SC_FLOPS] += flops, scal[SC_ROWS] += rows_swept;
+        return 1;
+    }
     if (!ok) {
         if (tid == 0) {
             atomicCAS(&S.status[mission], 0, (int)RBP_ERR_QP_FAILED);
@@ -2647,7 +2701,7 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
             scal[SC_PROF0 + 1] = 1000.0 * batch + fail_reason, scal[SC_PROF0 + 2] = it_count;  // why: 2 factor, 3 iteration cap
 #endif
         }
-        return;
+        return 0;
     }
     // ---- active-set polish
     if (S.p.polish && !polished) {
@@ -2667,6 +2721,10 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
         __syncthreads();
     }
     __syncthreads();
+    if (S.p.polish && !polished && nfar > 0) {  // refused, and rows the interior-point phase never saw exist: this point is not an answer
+        if (tid == 0) scal[SC_IPM_ITERS] += it_count, scal[SC_FLOPS] += flops, scal[SC_ROWS] += rows_swept;
+        return 1;
+    }
     const double kkt = polished ? red[12] : kkt_ipm;
     // objective of this batch: sum x' Q_p x  (cplex.getObjValue, :164)
     double obj = 0;
@@ -2695,6 +2753,33 @@ __device__ __forceinline__ void qp_batch_body(const DevSession& S, double* ws_ba
 #endif
     }
     PROF_FLUSH(scal);
+    return 0;
+}
+
+// the batch agents' control points back at the starting point of the first pass: build_dummy (dummy_kernel) for agents [first, first + nbmax)
+__device__ void restore_dummy(const DevSession& s, int mission, int first, int nbmax) {
+    const int N = s.N, MS = s.M, PS = MS + 1, M = s.Mk[mission], P = M + 1, oq = 6 * M;
+    const int nb = min(nbmax, N - first);
+    double* ctrl = s.ctrl + (size_t)mission * N * 3 * 6 * MS;
+    for (int it = threadIdx.x; it < nb * 3 * oq; it += QP_THREADS) {
+        const int j6 = it % oq, k = (it / oq) % 3, qi = first + it / (3 * oq);
+        const int m = j6 / 6, j = j6 % 6;
+        const float* tr = s.init_traj + (size_t)mission * N * PS * 3 + (size_t)qi * P * 3;
+        const int a = (j < 3) ? 0 : 1;
+        ctrl[((size_t)qi * 3 + k) * oq + j6] = (1 - a) * (double)tr[3 * m + k] + a * (double)tr[3 * (m + 1) + k];
+    }
+}
+
+// the second attempt of a batch QP, every row near (see qp_batch_kernel): a stand-alone copy of the body; Sg = the kernel's copy of the
+// session struct in LDS (a reference to memory where the body expects a struct in registers misbehaved: it gets a private copy)
+__device__ __noinline__ void qp_batch_again(const DevSession* Sg, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax, int reset_cost,
+                                            int lds_doubles, int pass_index) {
+    const DevSession S = *Sg;
+    mission = uni(mission), batch = uni(batch), nbmax = uni(nbmax);
+    restore_dummy(S, mission, batch * nbmax, nbmax);
+    __threadfence_block();
+    __syncthreads();
+    (void)qp_batch_body(S, uni(ws_base), ws_stride, mission, batch, nbmax, uni(reset_cost), uni(lds_doubles), uni(pass_index), 1e300);
 }
 
 // One workgroup per mission runs the WHOLE Gauss-Seidel schedule of solveQP (rbp_planner.hpp:140-203: `passes` sweeps
@@ -2707,11 +2792,30 @@ __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(D
     // the last mission does, and a long one started late leaves most of the chip idle behind it
     const int mission = S.qp_order ? __builtin_amdgcn_readfirstlane(S.qp_order[blockIdx.x]) : (int)blockIdx.x;
     const long long t_start = wall_clock64();
+    // First Gauss-Seidel pass, polish on: the interior-point phase works on the reduced row set (QP_FAR_SLACK).  A batch QP that does not end
+    // polished that way is solved again from its starting point -- the reference's dummy control points -- with every row: rare (1 of the 800
+    // batch QPs of the 50-map sweep at 0.7 m), and kept OUT OF LINE in a stand-alone copy of the body (qp_batch_again).  The call site costs
+    // every batch QP ~3 % (state kept across the call; 127.7 k against 131.5 k agent-trajectories/s with the call compiled out) whichever way
+    // the session struct travels (by value 124.0 k, from LDS 127.7 k, from device memory 126.8 k); measured alternatives were worse: a loop of
+    // two attempts around the inlined body -3.6 %, the rest of the schedule in a function called in tail position 121.5 k, one more trip
+    // through the batch loop ("redo" flag) 87 k in the 256-thread build.
+    __shared__ DevSession S_lds;  // (for the out-of-line second attempt only)
+    if (threadIdx.x == 0) S_lds = S;
+    __syncthreads();
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
-            qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it);
+            const double far_R = (it == 0 && S.p.polish) ? (double)QP_FAR_SLACK : 1e300;
+            const int again = qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R);
             __threadfence_block();
             __syncthreads();
+            if (again) {
+#ifndef QP_PROFILE
+                if (threadIdx.x == 0) S.scalars[(size_t)mission * SC_N + SC_PROF0 + 3] += 1;  // diagnostic: batch QPs solved a second time with every row
+#endif
+                qp_batch_again(&S_lds, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it);
+                __threadfence_block();
+                __syncthreads();
+            }
         }
     if (S.qp_cost && threadIdx.x == 0) S.qp_cost[mission] = (unsigned long long)(wall_clock64() - t_start) + 1;
 }

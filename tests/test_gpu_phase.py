@@ -1,7 +1,8 @@
 """The PHASE-SPLIT schedule of the batch QPs (kernels/qp_phase.inc, rbp_solver_opts.qp_schedule = 2): chip-wide row sweeps as kernels of
 their own, one workgroup per mission for chains and polish, a fixed budget of rounds enqueued without synchronisation.  Same device
 functions as qp_batch_kernel (one workgroup per mission for everything, the default); only the block reductions of a sweep are summed in a
-different order, so both schedules land on the same KKT-certified optimum with the same iteration counts.  Needs an MI355X."""
+different order (and the monolith's interior-point phase works on the reduced row set of QP_FAR_SLACK in the first pass, the phase split on
+every row): both schedules land on the same KKT-certified optimum.  Needs an MI355X."""
 import numpy as np
 import pytest
 
@@ -29,8 +30,8 @@ def _run(worlds, missions, p, inits, times=1, **opts):
 @pytest.mark.parametrize("agents,batch,iteration,maps", [(64, 4, 1, [1, 2, 46, 4, 5, 6]), (16, 8, 3, [3, 9]), (8, 3, 1, [5])])
 def test_phase_split_equals_one_workgroup_per_mission(agents, batch, iteration, maps):
     """ragged session (M = 34..37), a last batch shorter than the others (8 agents in batches of 3), several Gauss-Seidel passes with the
-    polish-first shortcut, the tiled path (batches of 8): the two schedules agree to 1e-7 m, solve and polish the same QPs in the same
-    number of interior-point iterations; two groups of missions on two streams give the same bits as one"""
+    polish-first shortcut, the tiled path (batches of 8): the two schedules agree to 2e-7 m, solve and polish the same QPs; two groups of
+    missions on two streams give the same bits as one"""
     p = Param.test_sweep(batch_size=batch, iteration=iteration)
     m = host.load_mission(f"mission_{agents}agents_15.json")
     worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
@@ -40,8 +41,7 @@ def test_phase_split_equals_one_workgroup_per_mission(agents, batch, iteration, 
     _, (g2,) = _run(worlds, [m] * len(maps), p, inits, qp_schedule=2, qp_groups=2)
     for a, b in zip(mono, phase):
         assert b.qp_solves == a.qp_solves and b.qp_unpolished == 0 and a.qp_unpolished == 0
-        assert b.qp_iterations == a.qp_iterations
-        assert np.abs(a.ctrl - b.ctrl).max() < 1e-7
+        assert np.abs(a.ctrl - b.ctrl).max() < 2e-7
         assert abs(a.total_cost - b.total_cost) <= 1e-8 * max(1.0, abs(a.total_cost))
         obj, veq, vbox, vrs = O.evaluate_ctrl(m, b)
         assert veq < 5e-8 and vbox < 1e-8 and vrs < 1e-8
