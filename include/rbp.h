@@ -174,6 +174,10 @@ typedef struct rbp_solver_opts {
     int32_t qp_block_order;        /* qp_schedule 1: 1 = a session that is run again starts its longest missions first; 0 = plain order */
     int32_t qp_groups;             /* qp_schedule 2: streams the missions are spread over (0 automatic, at most 8) */
     int32_t qp_rounds;             /* qp_schedule 2: round budget (0 automatic: 48 per batch QP of the schedule) */
+    double qp_far_slack;           /* qp_schedule 1, first Gauss-Seidel pass, polish on: 0.7 [m].  The interior-point phase of a batch QP leaves
+                                      out the frozen-neighbour rows whose slack at the starting point exceeds this for a whole (agent, segment)
+                                      group; the polish verifies EVERY row, and a batch QP that does not end polished on the reduced set is
+                                      solved again with every row -- the answer is the same certified optimum for any value.  <= 0: off */
 } rbp_solver_opts;
 void rbp_solver_opts_defaults(rbp_solver_opts* o);
 

@@ -79,7 +79,7 @@ class rbp_device_arrays(C.Structure):
 class rbp_solver_opts(C.Structure):
     _fields_ = [("size", C.c_int32), ("polish", C.c_int32), ("joint_wide_min_agents", C.c_int32), ("joint_corrector", C.c_int32),
                 ("joint_schedule", C.c_int32), ("qp_schedule", C.c_int32), ("qp_variant", C.c_int32), ("qp_block_order", C.c_int32),
-                ("qp_groups", C.c_int32), ("qp_rounds", C.c_int32)]
+                ("qp_groups", C.c_int32), ("qp_rounds", C.c_int32), ("qp_far_slack", C.c_double)]
 
 
 class rbp_mission_buf(C.Structure):

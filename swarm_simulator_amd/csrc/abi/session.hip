@@ -147,13 +147,14 @@ void rbp_solver_opts_defaults(rbp_solver_opts* o) {
     o->size = (int32_t)sizeof(*o);
     o->polish = 1, o->joint_wide_min_agents = 16, o->joint_corrector = 1, o->joint_schedule = 0;
     o->qp_schedule = 0, o->qp_variant = 0, o->qp_block_order = 1, o->qp_groups = 0, o->qp_rounds = 0;
+    o->qp_far_slack = 0.7;
 }
 
 static int check_solver_opts(const rbp_solver_opts* o) {
     if (!o) return fail(RBP_ERR_BAD_ARGUMENT, "null solver options");
     if (o->size != (int32_t)sizeof(rbp_solver_opts)) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts.size does not match this library (fill it with rbp_solver_opts_defaults)");
     if (o->joint_wide_min_agents < 0 || o->joint_schedule < 0 || o->joint_schedule > 2 || o->qp_schedule < 0 || o->qp_schedule > 2 ||
-        !(o->qp_variant == 0 || o->qp_variant == 2 || o->qp_variant == 4) || o->qp_groups < 0 || o->qp_rounds < 0)
+        !(o->qp_variant == 0 || o->qp_variant == 2 || o->qp_variant == 4) || o->qp_groups < 0 || o->qp_rounds < 0 || !(o->qp_far_slack == o->qp_far_slack))
         return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts: field out of range");
     return RBP_OK;
 }
@@ -297,7 +298,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
     d.p.iteration = param->iteration, d.p.time_scale = param->time_scale;
-    d.p.polish = 1;  // (rbp_solver_opts.polish of the run)
+    d.p.polish = 1, d.p.far_slack = 0.7;  // (rbp_solver_opts.polish / qp_far_slack of the run)
 
     Arena& A = s->arena;
     s->worlds_h.resize(K);
@@ -515,6 +516,7 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     }
     s->last_stages = stages;
     s->d.p.polish = o.polish ? 1 : 0;
+    s->d.p.far_slack = o.qp_far_slack;
     if (stages & RBP_STAGE_CORRIDOR) {
         int rc = launch_corridor(s->d, st);
         if (rc) return rc;

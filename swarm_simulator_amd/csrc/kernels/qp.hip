@@ -62,7 +62,8 @@
 // weight, no ratio test).  Correctness does not depend on the choice: the active-set polish verifies EVERY row of the full QP at the point it
 // proposes (far rows that come out violated join the candidates and the dual is solved again), and a batch QP whose polish is refused -- or
 // whose interior-point method fails -- while far rows exist is solved again from its starting point with every row near.  Applies to the
-// first Gauss-Seidel pass of the sequential schedule with the polish on; 1e300 = off.
+// first Gauss-Seidel pass of the sequential schedule with the polish on.  The value travels in rbp_solver_opts.qp_far_slack (DevParam::far_slack);
+// this is its default (abi/session.hip rbp_solver_opts_defaults).
 #define QP_FAR_SLACK 0.7  // (A/B on one box, 2000 missions resident: off 100.1 k, 1.0 m 123.2 k, 0.7 m 127.7 k, 0.5 m 127.2 k agent-trajectories/s;
                           // batch QPs solved twice on the 50-map sweep: 0 / 1 / 8 of 800; 0.25 m costs iterations: profiles/r05_ab_reduced_rows.txt)
 #endif
@@ -2804,7 +2805,7 @@ __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(D
     __syncthreads();
     for (int it = 0; it < passes; ++it)
         for (int l = 0; l < biter; ++l) {
-            const double far_R = (it == 0 && S.p.polish) ? (double)QP_FAR_SLACK : 1e300;
+            const double far_R = (it == 0 && S.p.polish && S.p.far_slack > 0.0) ? S.p.far_slack : 1e300;
             const int again = qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R);
             __threadfence_block();
             __syncthreads();

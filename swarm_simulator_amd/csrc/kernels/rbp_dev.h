@@ -38,6 +38,7 @@ struct DevParam {
     double box_xy_res, box_z_res, downwash;
     int sequential, batch_size, batch_iter, iteration, time_scale;
     int polish;  // 1: active-set polish after the interior-point solve (default)
+    double far_slack;  // rbp_solver_opts.qp_far_slack (kernels/qp.hip QP_FAR_SLACK); <= 0: every row near
 };
 
 // per-session pointers handed to kernels by value

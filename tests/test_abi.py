@@ -129,7 +129,7 @@ def test_solver_opts_defaults_and_checks():
     o = planner.solver_opts()
     assert o.size == C.sizeof(A.rbp_solver_opts) == planner.lib().rbp_sizeof(6)
     assert (o.polish, o.joint_wide_min_agents, o.joint_corrector, o.joint_schedule) == (1, 16, 1, 0)
-    assert (o.qp_schedule, o.qp_variant, o.qp_block_order, o.qp_groups, o.qp_rounds) == (0, 0, 1, 0, 0)
+    assert (o.qp_schedule, o.qp_variant, o.qp_block_order, o.qp_groups, o.qp_rounds, o.qp_far_slack) == (0, 0, 1, 0, 0, 0.7)
     bad = planner.solver_opts()
     bad.size = 8
     assert planner.lib().rbp_session_set_solver_opts(None, C.byref(bad)) == A.RBP_ERR_BAD_ARGUMENT   # (null session)

@@ -59,3 +59,36 @@ def test_phase_split_round_budget_fails_loudly():
     sess.run(A.RBP_STAGE_ALL)
     assert sess.download() == [A.RBP_ERR_QP_FAILED]
     sess.close()
+
+
+def test_reduced_row_set_is_the_same_optimum_for_any_radius():
+    """rbp_solver_opts.qp_far_slack (kernels/qp.hip QP_FAR_SLACK): the interior-point phase of a first-pass batch QP leaves out the frozen-
+    neighbour rows that are far from active at the starting point; the polish verifies EVERY row of the full QP, and a batch QP that does not
+    end polished on the reduced set is solved again with every row.  Off, the default 0.7 m, and 0.15 m -- where so many needed rows are
+    left out that second attempts actually happen (scalars slot 11 counts them) -- must give the same KKT-certified optimum, feasible for
+    every row of the reference's constraint sets."""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_64agents_15.json")
+    maps = [1, 13, 27, 46]
+    worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+    res, again = {}, {}
+    for R in (0.0, 0.7, 0.15):
+        plans = [g.clone_inputs() for g in inits]
+        sess = planner.Session(worlds, [m] * len(maps), p, plans, opts=planner.solver_opts(qp_schedule=1, qp_far_slack=R))
+        sess.run(A.RBP_STAGE_ALL)
+        assert sess.download() == [0] * len(maps)
+        again[R] = sess.scalars(12)[:, 11].sum()
+        sess.close()
+        res[R] = plans
+        for g in plans:
+            assert g.qp_solves == 16 and g.qp_unpolished == 0 and g.kkt_max < 1e-8
+            obj, veq, vbox, vrs = O.evaluate_ctrl(m, g)
+            assert veq < 5e-8 and vbox < 1e-8 and vrs < 1e-8
+    assert again[0.0] == 0
+    assert again[0.15] > 0, "the 0.15 m radius is meant to exercise the second attempt"
+    for R in (0.7, 0.15):
+        for a, b in zip(res[0.0], res[R]):
+            assert np.abs(a.ctrl - b.ctrl).max() < 5e-7
+            assert abs(a.total_cost - b.total_cost) <= 1e-8 * max(1.0, abs(a.total_cost))
+    assert sum(g.qp_iterations for g in res[0.7]) < sum(g.qp_iterations for g in res[0.0])
