@@ -2771,16 +2771,33 @@ __device__ void restore_dummy(const DevSession& s, int mission, int first, int n
     }
 }
 
-// the second attempt of a batch QP, every row near (see qp_batch_kernel): a stand-alone copy of the body; Sg = the kernel's copy of the
-// session struct in LDS (a reference to memory where the body expects a struct in registers misbehaved: it gets a private copy)
-__device__ __noinline__ void qp_batch_again(const DevSession* Sg, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax, int reset_cost,
-                                            int lds_doubles, int pass_index) {
+// The REST of a mission's schedule from batch (it0, l0) on, whose first attempt on the reduced row set failed (see qp_batch_kernel): that batch
+// again with every row, then the remaining batches and passes.  Sg: the kernel's copy of the session struct in LDS (the body was written for a
+// struct that lives in registers: it gets a private copy).
+__device__ __noinline__ void qp_finish_schedule(const DevSession* Sg, double* ws_base, size_t ws_stride, int mission, int passes, int biter, int nbmax,
+                                               int lds_doubles, int it0, int l0) {
     const DevSession S = *Sg;
-    mission = uni(mission), batch = uni(batch), nbmax = uni(nbmax);
-    restore_dummy(S, mission, batch * nbmax, nbmax);
-    __threadfence_block();
-    __syncthreads();
-    (void)qp_batch_body(S, uni(ws_base), ws_stride, mission, batch, nbmax, uni(reset_cost), uni(lds_doubles), uni(pass_index), 1e300);
+    ws_base = uni(ws_base), mission = uni(mission), passes = uni(passes), biter = uni(biter), nbmax = uni(nbmax), lds_doubles = uni(lds_doubles);
+    it0 = uni(it0), l0 = uni(l0);
+    for (int it = it0; it < passes; ++it)
+        for (int l = (it == it0 ? l0 : 0); l < biter; ++l) {
+            const bool failed = it == it0 && l == l0;
+            for (int attempt = failed ? 1 : 0; attempt < 2; ++attempt) {
+                if (attempt == 1) {
+#ifndef QP_PROFILE
+                    if (threadIdx.x == 0) S.scalars[(size_t)mission * SC_N + SC_PROF0 + 3] += 1;
+#endif
+                    restore_dummy(S, mission, l * nbmax, nbmax);
+                    __threadfence_block();
+                    __syncthreads();
+                }
+                const double far_R = (attempt == 0 && it == 0 && S.p.polish && S.p.far_slack > 0.0) ? S.p.far_slack : 1e300;
+                const int again = uni(qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R));
+                __threadfence_block();
+                __syncthreads();
+                if (!again) break;
+            }
+        }
 }
 
 // One workgroup per mission runs the WHOLE Gauss-Seidel schedule of solveQP (rbp_planner.hpp:140-203: `passes` sweeps
@@ -2795,29 +2812,27 @@ __global__ __launch_bounds__(QP_THREADS, QP_WAVES_PER_EU) void qp_batch_kernel(D
     const long long t_start = wall_clock64();
     // First Gauss-Seidel pass, polish on: the interior-point phase works on the reduced row set (QP_FAR_SLACK).  A batch QP that does not end
     // polished that way is solved again from its starting point -- the reference's dummy control points -- with every row: rare (1 of the 800
-    // batch QPs of the 50-map sweep at 0.7 m), and kept OUT OF LINE in a stand-alone copy of the body (qp_batch_again).  The call site costs
-    // every batch QP ~3 % (state kept across the call; 127.7 k against 131.5 k agent-trajectories/s with the call compiled out) whichever way
-    // the session struct travels (by value 124.0 k, from LDS 127.7 k, from device memory 126.8 k); measured alternatives were worse: a loop of
-    // two attempts around the inlined body -3.6 %, the rest of the schedule in a function called in tail position 121.5 k, one more trip
-    // through the batch loop ("redo" flag) 87 k in the 256-thread build.
-    __shared__ DevSession S_lds;  // (for the out-of-line second attempt only)
+    // batch QPs of the 50-map sweep at 0.7 m).  The batch loop itself holds NO call: when a first attempt fails the loop stops, and the rest
+    // of the mission's schedule -- that batch again with every row, then the remaining batches and passes -- runs out of line in
+    // qp_finish_schedule, a stand-alone copy of the body, after the loops.  Measured, 2000 missions resident (profiles/r05_ab_reduced_rows.txt):
+    // this 133.8 k agent-trajectories/s; a second attempt called from INSIDE the loop 127.7 .. 129.6 k (state kept across the call site,
+    // whichever way the session struct travels), a loop of two attempts around the inlined body ~123 k, a "redo" trip through the batch loop 87 k.
+    __shared__ DevSession S_lds;  // (for qp_finish_schedule only)
     if (threadIdx.x == 0) S_lds = S;
     __syncthreads();
-    for (int it = 0; it < passes; ++it)
+    int stop_it = -1, stop_l = 0;
+    for (int it = 0; it < passes && stop_it < 0; ++it)
         for (int l = 0; l < biter; ++l) {
             const double far_R = (it == 0 && S.p.polish && S.p.far_slack > 0.0) ? S.p.far_slack : 1e300;
             const int again = qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R);
             __threadfence_block();
             __syncthreads();
             if (again) {
-#ifndef QP_PROFILE
-                if (threadIdx.x == 0) S.scalars[(size_t)mission * SC_N + SC_PROF0 + 3] += 1;  // diagnostic: batch QPs solved a second time with every row
-#endif
-                qp_batch_again(&S_lds, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it);
-                __threadfence_block();
-                __syncthreads();
+                stop_it = it, stop_l = l;
+                break;
             }
         }
+    if (stop_it >= 0) qp_finish_schedule(&S_lds, ws_base, ws_stride, mission, passes, biter, nbmax, lds_doubles, stop_it, stop_l);
     if (S.qp_cost && threadIdx.x == 0) S.qp_cost[mission] = (unsigned long long)(wall_clock64() - t_start) + 1;
 }
 
