@@ -219,3 +219,43 @@ def test_longest_first_block_order_does_not_change_results():
     for a, b, c, d in zip(first, second, third, plain):
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a.view(np.uint64), c.view(np.uint64))
         assert np.array_equal(a.view(np.uint64), d.view(np.uint64))
+
+
+def test_qp_workspace_is_reserved_by_the_first_planner_run():
+    """a session that only runs the CORRIDOR stage reserves no QP workspace (round 4 cleared 0.35 GB per 64-agent joint mission
+    at session create); the first PLANNER run -- or rbp_session_reserve_workspace -- reserves it for the solver options then in force, and a
+    change of options that needs another layout (grid-wide joint solver <-> one workgroup) reserves anew."""
+    p = Param.test_sweep(sequential=False)
+    m = host.load_mission("mission_16agents_15.json")
+    w = host.load_world("map3.bt", p)
+    g = host.ecbs_plan(w, m, p)
+    sess = planner.Session([w], [m], p, [g])
+    sess.run(A.RBP_STAGE_CORRIDOR)
+    assert sess.download() == [0] and sess.workspace_bytes_per_mission() == 0
+    sess.reserve_workspace()
+    wide = sess.workspace_bytes_per_mission()
+    assert wide > 0
+    sess.run(A.RBP_STAGE_PLANNER)
+    assert sess.download() == [0] and g.qp_unpolished == 0
+    ctrl_wide = g.ctrl.copy()
+    sess.set_solver_opts(joint_wide_min_agents=0)      # the same joint QP on one workgroup: another workspace layout
+    sess.reset()
+    sess.run(A.RBP_STAGE_ALL)
+    assert sess.download() == [0]
+    one = sess.workspace_bytes_per_mission()
+    assert 0 < one != wide
+    assert np.abs(g.ctrl - ctrl_wide).max() < CTRL_TOL
+    sess.close()
+
+
+def test_corridor_lds_need_is_checked_at_session_create():
+    """sfc_kernel keeps box_log [max_boxes][M + 1] per agent of a workgroup in LDS; a plan whose max_boxes does not fit is refused
+    by rbp_session_create with the numbers in the message, not by the launch with a generic HIP error"""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_8agents_15.json")
+    w = host.load_world("map5.bt", p)
+    g = host.ecbs_plan(w, m, p)
+    from swarm_simulator_amd.types import PlanResult
+    big = PlanResult(g.init_traj.copy(), g.T.copy(), 2000)   # box_log would be 8 agents x 2000 x (M + 1) x 2 bytes > 160 KB
+    with pytest.raises(RuntimeError, match="LDS"):
+        planner.Session([w], [m], p, [big])
