@@ -1558,8 +1558,9 @@ JLayout jq_layout(int N, int MS) {
     L.o_acc = take((size_t)d.nch * 12 * ncp);
     L.o_Y = take((size_t)2 * d.nblk * JTT), L.o_P = take((size_t)4 * JTT);
     L.o_scr = take((size_t)2 * d.nkp * d.nkp);
-    L.o_inv = take((size_t)d.nj * d.nkp * d.nkp);
-    L.o_pol = take(pol_layout(N, MS).total);
+    const PolLayout PL = pol_layout(N, MS);
+    L.o_inv = take(std::max((size_t)d.nj * d.nkp * d.nkp, PL.big_total));  // (the polish's matrices overlay the inverses: jqp_polish.inc pol_layout)
+    L.o_pol = take(PL.total);
     L.o_rhsc = take((size_t)d.nj * d.nkp), L.o_dx2 = take(3 * ncp), L.o_tb = take(6 * ncp), L.o_tp = take(nrow);
     L.stride = o;
     return L;
