@@ -254,6 +254,26 @@ def joint_leg(agents=64):
     status = sess.download(stream)
     ws = sess.workspace_bytes_per_mission()
     sess.close()
+    # the same sweep as two sessions of 25 missions in flight at once (rbp_session_run_async: each solve on its session's own thread and
+    # stream; one session's kernels fill the other's once-per-round synchronisation gaps)
+    halves = [planner.Session(worlds[a:b], [m] * 25, p, plans[a:b]) for a, b in ((0, 25), (25, 50))]
+    asyn = None
+    for rep in range(2):
+        for s2 in halves:
+            s2.reset(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s2 in halves:
+            s2.run_async(A.RBP_STAGE_ALL, stream)
+        t_call = time.perf_counter() - t0
+        for s2 in halves:
+            s2.wait()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        st2 = sum((s2.download(stream) for s2 in halves), [])
+        asyn = {"sessions_in_flight": 2, "value": (50 * m.qn / t_all) if not any(st2) else None, "ms": 1e3 * t_all, "calls_return_after_ms": 1e3 * t_call}
+    for s2 in halves:
+        s2.close()
     tflops = ct["qp_flops"] / (planner_ms * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": "jq_update(_bulk) + jq_panel (joint QP, kernels/jqp.hip)", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "flops_per_sweep": ct["qp_flops"],
@@ -275,7 +295,7 @@ def joint_leg(agents=64):
         pass
     return {"joint_single_mission_ms": single["two_calls_ms"], "joint_single_mission": single,
             "joint_sweep_value": (50 * m.qn / dt) if not any(status) else None, "joint_sweep_ms": 1e3 * dt,
-            "joint_workspace_bytes_per_mission": ws, "roofline_joint": roof}
+            "joint_sweep_async": asyn, "joint_workspace_bytes_per_mission": ws, "roofline_joint": roof}
 
 
 def sweep_phase_rate(K, agents, resident_wgs=512):

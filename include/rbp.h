@@ -163,7 +163,7 @@ typedef struct rbp_solver_opts {
     int32_t polish;                /* 1: every QP ends with the active-set polish (the certified optimum); 0: the interior-point answer
                                       with its reported KKT residual (diagnostics) */
     int32_t joint_wide_min_agents; /* 16: a joint QP (plan/sequential = false) of at least this many agents runs on the grid-wide
-                                      solver (kernels/jqp.hip, no limit on N, `run` synchronises); fewer agents -- or 0 = never --
+                                      solver (kernels/jqp.hip, no limit on N, `run` synchronises -- rbp_session_run_async does not); fewer agents -- or 0 = never --
                                       run on one workgroup per mission (<= 64 agents, `run` only enqueues) */
     int32_t joint_corrector;       /* 1: one centrality corrector per interior-point iteration of the grid-wide solver */
     int32_t joint_schedule;        /* 0: automatic; 1: look-ahead tile sweep (few missions); 2: bulk tile sweep (many missions) */
@@ -186,6 +186,16 @@ void rbp_solver_opts_defaults(rbp_solver_opts* o);
 int rbp_session_create(rbp_session** out, int device, int K, const rbp_world* worlds, const rbp_mission* missions,
                        const rbp_param* param, const rbp_plan* plans);
 int rbp_session_run(rbp_session* s, int stages, void* stream);
+/* `run` only enqueues on `stream`, with ONE exception: the PLANNER stage of a joint plan on the grid-wide solver (kernels/jqp.hip,
+ * rbp_solver_opts.joint_wide_min_agents), whose host loop learns once per interior-point round whether any mission still iterates --
+ * there `run` returns when the solve has ended.  rbp_session_run_async is the same call without that exception: the stages before the
+ * joint solve are enqueued on `stream`, the solve itself proceeds on a thread and a stream of the session's own (ordered after `stream`'s
+ * work so far by an event), and the call returns at once -- the caller overlaps it with host work (the next mission's ECBS) or with
+ * other sessions.  Every later call on the session (download, counters, scalars, reset, run, destroy ...) first waits for the solve;
+ * rbp_session_wait does only that and returns the solve's status.  What the caller enqueues on `stream` itself after run_async is NOT
+ * ordered after the solve.  For every other session rbp_session_run_async is rbp_session_run. */
+int rbp_session_run_async(rbp_session* s, int stages, void* stream);
+int rbp_session_wait(rbp_session* s);
 /* solver options of this session (default: the context's, else rbp_solver_opts_defaults).  The QP workspace is reserved by the first
  * PLANNER run, for the options then in force: a session that only runs the CORRIDOR stage reserves none. */
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o);

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../kernels/jqp.h"
@@ -103,7 +104,22 @@ struct rbp_session {
     hipEvent_t gevent[QP_MAX_GROUPS + 1] = {};
     int n_gstream = 0;
     int last_stages = 0;      // stages of the last rbp_session_run (time_scale only concerns a run that included the planner)
+    // rbp_session_run_async of a grid-wide joint session: the solver's host loop (one synchronisation per interior-point round) runs on a
+    // thread and a stream of the session's own; every later call on the session joins it first (join_worker)
+    std::thread worker;
+    int worker_rc = RBP_OK;
+    hipStream_t jstream = nullptr;
+    hipEvent_t jev_in = nullptr;
 };
+
+// waits for the session's asynchronous joint run, if one is in flight; reports its error once
+static int join_worker(rbp_session* s) {
+    if (!s->worker.joinable()) return RBP_OK;
+    s->worker.join();
+    const int rc = s->worker_rc;
+    s->worker_rc = RBP_OK;
+    return rc ? fail(rc, "joint QP (asynchronous run): HIP error") : RBP_OK;
+}
 
 extern "C" {
 
@@ -405,6 +421,7 @@ int rbp_session_create_in(rbp_ctx* ctx, rbp_session** out, int K, const rbp_worl
 // stage overwrote them.
 int rbp_session_reset(rbp_session* s, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
     hipStream_t st = (hipStream_t)stream;
     const DevSession& d = s->d;
     const int K = d.K, N = d.N, M = d.M, MB = d.max_boxes;
@@ -424,6 +441,7 @@ int rbp_session_reset(rbp_session* s, void* stream) {
 
 int rbp_session_set_agent_range(rbp_session* s, int32_t agent_begin, int32_t agent_end) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
     if (agent_begin < 0 || agent_end < agent_begin || agent_end > s->d.N) return fail(RBP_ERR_BAD_ARGUMENT, "agent range outside [0, N]");
     s->d.agent_begin = agent_begin, s->d.agent_end = agent_end;
     return RBP_OK;
@@ -493,20 +511,24 @@ size_t rbp_session_workspace_bytes(rbp_session* s) { return s && s->qp_ws ? s->q
 
 int rbp_session_reserve_workspace(rbp_session* s, void* stream) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
     HIP_TRY(hipSetDevice(s->device));
     return ensure_planner_workspace(s, (hipStream_t)stream);
 }
 
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
     int rc = check_solver_opts(o);
     if (rc) return rc;
     s->opts = *o;
     return RBP_OK;
 }
 
-int rbp_session_run(rbp_session* s, int stages, void* stream) {
+// `async`: a grid-wide joint PLANNER stage is handed to the session's worker thread (everything else only enqueues anyway)
+static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(s->device));
     const rbp_solver_opts& o = s->opts;
@@ -528,6 +550,29 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
         int rc = RBP_OK;
         JointOpts jo;
         jo.corrector = o.joint_corrector ? 1 : 0, jo.schedule = o.joint_schedule;
+        if (async) {
+            // rbp_session_run_async: the host loop moves to a thread and a stream of the session's own, ordered after what the caller's
+            // stream holds so far (inputs, the CORRIDOR stage, the prologue) by an event
+            if (!s->jstream) {
+                HIP_TRY(hipStreamCreateWithFlags(&s->jstream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&s->jev_in, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(s->jev_in, st));
+            HIP_TRY(hipGetLastError());
+            s->worker_rc = RBP_OK;
+            s->worker = std::thread([s, jo]() {
+                int wrc = RBP_OK;
+                hipStream_t js = s->jstream;
+                if (hipSetDevice(s->device) != hipSuccess || hipStreamWaitEvent(js, s->jev_in, 0) != hipSuccess) wrc = RBP_ERR_HIP;
+                if (!wrc && s->d.p.iteration > 0) wrc = launch_planner_joint(s->d, s->qp_ws, js, &s->joint_stats, jo);
+                if (!wrc) {
+                    launch_planner_epilogue(s->d, js);
+                    if (hipStreamSynchronize(js) != hipSuccess || hipGetLastError() != hipSuccess) wrc = RBP_ERR_HIP;
+                }
+                s->worker_rc = wrc;
+            });
+            return RBP_OK;
+        }
         if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats, jo);
         if (rc) return fail(rc, "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
@@ -560,8 +605,16 @@ int rbp_session_run(rbp_session* s, int stages, void* stream) {
     return RBP_OK;
 }
 
+int rbp_session_run(rbp_session* s, int stages, void* stream) { return run_impl(s, stages, stream, false); }
+int rbp_session_run_async(rbp_session* s, int stages, void* stream) { return run_impl(s, stages, stream, true); }
+int rbp_session_wait(rbp_session* s) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    return join_worker(s);
+}
+
 int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream) {
     if (!s || !plans) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    if (int jrc = join_worker(s)) return jrc;
     hipStream_t st = (hipStream_t)stream;
     const DevSession& d = s->d;
     const int K = d.K, N = d.N, M = d.M, MB = d.max_boxes, P = M + 1, oq = 6 * M;
@@ -659,6 +712,7 @@ int rbp_session_device_arrays(rbp_session* s, int32_t mission, rbp_device_arrays
 
 int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
     if (!s || !out) return fail(RBP_ERR_BAD_ARGUMENT, "null argument");
+    if (int jrc = join_worker(s)) return jrc;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     const int K = s->d.K;
@@ -682,6 +736,7 @@ int rbp_session_counters(rbp_session* s, rbp_counters* out, void* stream) {
 
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream) {
     if (!s || !out || n <= 0 || n > SC_N) return fail(RBP_ERR_BAD_ARGUMENT, "bad argument");
+    if (int jrc = join_worker(s)) return jrc;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     std::vector<double> sc((size_t)s->d.K * SC_N);
@@ -692,6 +747,12 @@ int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream) {
 
 void rbp_session_destroy(rbp_session* s) {
     if (!s) return;
+    (void)join_worker(s);
+    if (s->jstream) {
+        (void)hipSetDevice(s->device);
+        (void)hipStreamDestroy(s->jstream);
+        (void)hipEventDestroy(s->jev_in);
+    }
     if (s->n_gstream > 0) {
         (void)hipSetDevice(s->device);
         (void)hipEventDestroy(s->gevent[0]);

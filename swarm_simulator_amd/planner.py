@@ -92,6 +92,8 @@ def lib():
         L.rbp_session_create.argtypes = [P(C.c_void_p), C.c_int, C.c_int, P(A.rbp_world), P(A.rbp_mission), P(A.rbp_param),
                                          P(A.rbp_plan)]
         L.rbp_session_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rbp_session_run_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rbp_session_wait.argtypes = [C.c_void_p]
         L.rbp_session_download.argtypes = [C.c_void_p, P(A.rbp_plan), A.c_int32_p, C.c_void_p]
         L.rbp_session_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.rbp_session_counters.argtypes = [C.c_void_p, P(A.rbp_counters), C.c_void_p]
@@ -125,7 +127,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
-    "rbp_session_run", "rbp_session_set_agent_range",
+    "rbp_session_run", "rbp_session_run_async", "rbp_session_wait", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
     "rbp_session_device_arrays",
     "rbp_version", "rbp_abi_version", "rbp_sizeof", "rbp_release_thread_context",
@@ -276,6 +278,18 @@ class Session:
         rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))
         if rc:
             raise RuntimeError(f"rbp_session_run rc={rc}: {last_error()}")
+
+    def run_async(self, stages=A.RBP_STAGE_ALL, stream=None):
+        """`run` that returns at once for a grid-wide joint session too (the solve proceeds on a library thread; `wait`, `download`
+        and every other call on the session wait for it): include/rbp.h rbp_session_run_async"""
+        rc = lib().rbp_session_run_async(self._h, stages, C.c_void_p(stream or 0))
+        if rc:
+            raise RuntimeError(f"rbp_session_run_async rc={rc}: {last_error()}")
+
+    def wait(self):
+        rc = lib().rbp_session_wait(self._h)
+        if rc:
+            raise RuntimeError(f"rbp_session_wait rc={rc}: {last_error()}")
 
     def set_agent_range(self, agent_begin: int, agent_end: int):
         rc = lib().rbp_session_set_agent_range(self._h, agent_begin, agent_end)

@@ -51,10 +51,14 @@ joint)
   cd /tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/jkt -- $J --missions-per-gpu 200 --steps 1 --warmup 1 > $OUT/jkt.log 2>&1 < /dev/null
   timeout 900 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/jpmc -- $J --missions-per-gpu 200 --steps 1 --warmup 1 > $OUT/jpmc.log 2>&1 < /dev/null
+  for c in FETCH_SIZE WRITE_SIZE; do timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/jpmc_$c -- $J --missions-per-gpu 200 --steps 1 --warmup 1 > $OUT/jpmc_$c.log 2>&1 < /dev/null; done
   cd $R
   f=$(find $OUT/jkt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/joint_kernel_stats.csv
-  agg $OUT/jpmc "jq_update_bulk|jq_update|jq_panel|jq_pivot0|jq_mv|jq_prep|jq_sweep" > $OUT/joint_pmc.txt 2>&1
-  rm -rf $OUT/jkt $OUT/jpmc
+  python tools/joint_kernel_json.py $OUT/joint_kernel_stats.csv $OUT/joint_bench_200.log $OUT/joint_kernel.json > /dev/null 2>&1
+  KL="jq_update_bulk|jq_update|jq_panel|jq_pivot0|jq_mv|jq_prep|jq_sweep"
+  { agg $OUT/jpmc "$KL"; echo "---- HBM side, KB per dispatch as reported (FETCH_SIZE counts half of the bytes of wide reads on gfx950: MI355X_MICROARCH.md)"; agg $OUT/jpmc_FETCH_SIZE "$KL"; agg $OUT/jpmc_WRITE_SIZE "$KL"; } > $OUT/joint_pmc.txt 2>&1
+  rm -rf $OUT/jkt $OUT/jpmc $OUT/jpmc_FETCH_SIZE $OUT/jpmc_WRITE_SIZE
+  timeout 600 python tools/r05_joint_async_ab.py > $OUT/joint_async_ab.txt 2>&1 < /dev/null
   for cfg in "64 3" "256 1"; do set -- $cfg; timeout 600 python tools/gpu_joint_wide.py $1 $2 --no-wg --reps 3 > $OUT/joint_single_$1.log 2>&1 < /dev/null; done
   ;;
 other) bash tools/collect_other_configs.sh r05 > /dev/null 2>&1 ;;
