@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--qp-groups", type=int, default=0, help="rbp_solver_opts.qp_groups (phase split: streams)")
     ap.add_argument("--qp-variant", choices=["auto", "w2", "w4"], default="auto", help="rbp_solver_opts.qp_variant (A/B runs)")
     ap.add_argument("--qp-far-slack", type=float, default=None, help="rbp_solver_opts.qp_far_slack [m] (A/B runs; default: the library's 0.7)")
+    ap.add_argument("--joint-schedule", type=int, default=0, help="rbp_solver_opts.joint_schedule (A/B runs: 2 = bulk, 3 = bulk with two pivot tiles per pass)")
     ap.add_argument("--plain-order", action="store_true", help="rbp_solver_opts.qp_block_order = 0 (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-mission latency leg (profiling runs: keeps the kernel list clean)")
@@ -417,6 +418,7 @@ def main():
                                qp_variant={"auto": 0, "w2": 2, "w4": 4}[args.qp_variant], qp_block_order=0 if args.plain_order else 1)
     if args.qp_far_slack is not None:
         opts.qp_far_slack = args.qp_far_slack
+    opts.joint_schedule = args.joint_schedule
     sess = planner.Session(worlds, [mission] * K, param, plans, device=local_rank, opts=opts)
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -166,7 +166,9 @@ typedef struct rbp_solver_opts {
                                       solver (kernels/jqp.hip, no limit on N, `run` synchronises -- rbp_session_run_async does not); fewer agents -- or 0 = never --
                                       run on one workgroup per mission (<= 64 agents, `run` only enqueues) */
     int32_t joint_corrector;       /* 1: one centrality corrector per interior-point iteration of the grid-wide solver */
-    int32_t joint_schedule;        /* 0: automatic; 1: look-ahead tile sweep (few missions); 2: bulk tile sweep (many missions) */
+    int32_t joint_schedule;        /* 0: automatic; 1: look-ahead tile sweep (few missions); 2: bulk tile sweep (many missions); 3: bulk with
+                                      two pivot tiles per pass over a knot's matrix (half the HBM traffic of the update; pays only with
+                                      hundreds of resident missions: DESIGN.md 3.5) */
     int32_t qp_schedule;           /* batch QPs of the sequential schedule: 0 automatic; 1: one workgroup per mission runs everything
                                       (qp_batch_kernel); 2: phase split -- chip-wide row sweeps as kernels of their own
                                       (kernels/qp_phase.inc) */

@@ -169,7 +169,7 @@ void rbp_solver_opts_defaults(rbp_solver_opts* o) {
 static int check_solver_opts(const rbp_solver_opts* o) {
     if (!o) return fail(RBP_ERR_BAD_ARGUMENT, "null solver options");
     if (o->size != (int32_t)sizeof(rbp_solver_opts)) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts.size does not match this library (fill it with rbp_solver_opts_defaults)");
-    if (o->joint_wide_min_agents < 0 || o->joint_schedule < 0 || o->joint_schedule > 2 || o->qp_schedule < 0 || o->qp_schedule > 2 ||
+    if (o->joint_wide_min_agents < 0 || o->joint_schedule < 0 || o->joint_schedule > 3 || o->qp_schedule < 0 || o->qp_schedule > 2 ||
         !(o->qp_variant == 0 || o->qp_variant == 2 || o->qp_variant == 4) || o->qp_groups < 0 || o->qp_rounds < 0 || !(o->qp_far_slack == o->qp_far_slack))
         return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts: field out of range");
     return RBP_OK;

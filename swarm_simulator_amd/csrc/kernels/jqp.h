@@ -23,6 +23,7 @@ struct JArgs {
     int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
     int trace;      // RBP_JOINT_TRACE: device-side diagnostics of the polish's acceptance test
     int gond_only;  // launches of the centrality corrector: only missions with ST_GACT set take part
+    int sweep2;     // tile sweep of the knots (kind 0): 1 = two pivot tiles per pass (jq_pivot2 / jq_panel2 / jq_update2_bulk), 0 = one
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;
     double gond[3];  // centrality corrector: extra step length asked for, share of it that must be gained, step length below which it is tried
@@ -42,7 +43,7 @@ struct JointStats {
 
 struct JointOpts {  // what rbp_solver_opts says about the grid-wide joint solver
     int corrector = 1;  // one centrality corrector per interior-point iteration
-    int schedule = 0;   // tile sweep: 0 automatic, 1 look-ahead, 2 bulk
+    int schedule = 0;   // tile sweep: 0 automatic, 1 look-ahead, 2 bulk, 3 bulk with two pivot tiles per pass (opt-in)
 };
 
 JLayout jq_layout(int N, int MS);

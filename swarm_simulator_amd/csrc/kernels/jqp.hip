@@ -868,8 +868,9 @@ __device__ __forceinline__ Chain chain_step(const JDims& d, int chain, int s, bo
     }
     return c;
 }
-// ping-pong buffers of the sweep: X[0] = the knot's slot in `inv`, X[1] = the chain's scratch; step k reads X[(k + p0) & 1] and writes
-// the other; p0 = nblk & 1 makes the last step land in X[0]
+// ping-pong buffers of the sweep: X[0] = the knot's slot in `inv`, X[1] = the chain's scratch; pass t reads X[(t + p0) & 1] and writes
+// the other; p0 = (number of passes) & 1 makes the last pass land in X[0]
+__device__ __forceinline__ int sweep_parity0(const JArgs& A, int nblk) { return (A.sweep2 ? (nblk + 1) / 2 : nblk) & 1; }
 __device__ __forceinline__ double* sweep_buf(const Ws& w, const JDims& d, const JLayout& L, int chain, int jj, int which) {
     return which == 0 ? w.inv + (size_t)jj * L.nkpS * L.nkpS : w.scr + (size_t)chain * L.nkpS * L.nkpS;
 }
@@ -883,7 +884,8 @@ struct SweepCtx {
     double* dst;        // X[(k + p0 + 1) & 1]
     double* Pk;         // pivot inverse of step k
     double* Pn;         // ... of step k + 1 (look-ahead)
-    double* Y;          // panel
+    double* P2;         // double step (k, k + 1): the three tiles P00, P10, P11 of the pivot block's inverse
+    double* Y;          // panel (double step: two tiles per block row)
     double* bad;        // counter of non-positive pivots
     const double* G;    // polish (kind 1): the matrix before the sweep (tile-major): its diagonal scales the deletion threshold; else nullptr
 };
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(256) void jq_prep(JArgs A, int s, int mid) {
     const Chain c = chain_step(d, chain, s, mid != 0);
     if (!c.active) return;
     const int jj = c.jj, j = jj + 1, nblk = d.nblk, oq = d.oq, n3 = 3 * N;
-    double* X = sweep_buf(w, d, A.L, chain, jj, (nblk & 1));
+    double* X = sweep_buf(w, d, A.L, chain, jj, sweep_parity0(A, nblk));
     const float* normals = S.rsfc_normal + (size_t)mission * S.npair * MS * 3;
     const int t = blockIdx.x * 256 + threadIdx.x;
     // identity padding (rows / columns nk .. nkp-1)
@@ -1368,6 +1370,252 @@ __global__ __launch_bounds__(256, 3) void jq_update_bulk(JArgs A, int kind, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Double steps of the bulk schedule: the pivots (k, k + 1) in ONE pass over the matrix.  jq_update_bulk is bound by HBM, not by the MFMA
+// (profiles/r05_joint_pmc.txt: 1.6 GB of reads and writes per 286 us launch = 5.6 TB/s at 200 resident missions): every pass reads and
+// writes the knot's whole lower triangle for a rank-64 update.  Sweeping on the 128 x 128 pivot block [B_kk B_k+1,k'; B_k+1,k B_k+1,k+1]
+// is the same two sweep steps composed -- P2 = block^-1, Y2_J = [B_Jk B_J,k+1] P2, (I, J) <- B_IJ - Y2_I [B_Jk B_J,k+1]' -- with half the
+// passes over the matrix per unit of arithmetic.
+// ------------------------------------------------------------------------------------------------------------------------
+// P2 by block elimination in one workgroup: Pa = B_kk^-1, W = B_k+1,k Pa, Ps = (B_k+1,k+1 - W B_k+1,k')^-1,
+// P11 = Ps, P10 = -Ps W, P00 = Pa + W' Ps W.  The four 64^3 products run on plain FMAs out of LDS (a few microseconds per knot and pass).
+__global__ __launch_bounds__(256) void jq_pivot2(JArgs A, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y, tid = threadIdx.x;
+    const Ws w = carve(A, mission);
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
+    if (!c.active || k + 1 >= c.nblk) return;
+    extern __shared__ double lds2[];  // Am, Bm, Wm: 3 x JT x LDA doubles
+    __shared__ InvScratch sc;
+    __shared__ int bad;
+    double *Am = lds2, *Bm = lds2 + JT * LDA, *Wm = lds2 + 2 * JT * LDA;
+    const int nblk = c.nblk;
+    const double* t00 = c.src + ((size_t)k * nblk + k) * JTT;
+    const double* t10 = c.src + ((size_t)(k + 1) * nblk + k) * JTT;
+    const double* t11 = c.src + ((size_t)(k + 1) * nblk + k + 1) * JTT;
+    double *P00 = c.P2, *P10 = c.P2 + JTT, *P11 = c.P2 + 2 * JTT;
+    if (tid == 0) bad = 0;
+    for (int i = tid; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = t00[i], Bm[(i >> 6) * LDA + (i & 63)] = t10[i];
+    __syncthreads();
+    inv64_lds(Am, &sc, &bad);  // Am = -Pa
+    double pa[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = tid + 256 * n, r = i >> 6, cc = i & 63;
+        pa[n] = -0.5 * (Am[r * LDA + cc] + Am[cc * LDA + r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = tid + 256 * n;
+        Am[(i >> 6) * LDA + (i & 63)] = pa[n];
+    }
+    __syncthreads();
+    const int r0 = 4 * (tid >> 4), c0 = 4 * (tid & 15);
+    double acc[4][4];
+    // MODE 0: X[r][m] Yv[m][c]   1: X[r][m] Yv[c][m]   2: X[m][r] Yv[m][c]
+#define JQ_MM(MODE, X, Yv)                                                                            \
+    do {                                                                                              \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) _Pragma("unroll") for (int y = 0; y < 4; ++y) acc[x][y] = 0.0; \
+        for (int m = 0; m < JT; ++m) {                                                                \
+            double a[4], b[4];                                                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) a[x] = (MODE) == 2 ? (X)[m * LDA + r0 + x] : (X)[(r0 + x) * LDA + m]; \
+            _Pragma("unroll") for (int y = 0; y < 4; ++y) b[y] = (MODE) == 1 ? (Yv)[(c0 + y) * LDA + m] : (Yv)[m * LDA + c0 + y]; \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) _Pragma("unroll") for (int y = 0; y < 4; ++y) acc[x][y] = fma(a[x], b[y], acc[x][y]); \
+        }                                                                                             \
+    } while (0)
+    JQ_MM(0, Bm, Am);  // W = B10 Pa
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Wm[(r0 + x) * LDA + c0 + y] = acc[x][y];
+    __syncthreads();
+    JQ_MM(1, Wm, Bm);  // W B10'
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Am[(r0 + x) * LDA + c0 + y] = t11[(size_t)(r0 + x) * JT + c0 + y] - acc[x][y];
+    __syncthreads();
+    inv64_lds(Am, &sc, &bad);  // Am = -Ps
+    double ps[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = tid + 256 * n, r = i >> 6, cc = i & 63;
+        ps[n] = -0.5 * (Am[r * LDA + cc] + Am[cc * LDA + r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = tid + 256 * n;
+        Am[(i >> 6) * LDA + (i & 63)] = ps[n];
+        P11[i] = ps[n];
+    }
+    __syncthreads();
+    JQ_MM(0, Am, Wm);  // V = Ps W
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Bm[(r0 + x) * LDA + c0 + y] = acc[x][y], P10[(size_t)(r0 + x) * JT + c0 + y] = -acc[x][y];
+    __syncthreads();
+    JQ_MM(2, Wm, Bm);  // W' V
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Am[(r0 + x) * LDA + c0 + y] = acc[x][y];
+    __syncthreads();
+#undef JQ_MM
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        const int i = tid + 256 * n, r = i >> 6, cc = i & 63;
+        P00[i] = pa[n] + 0.5 * (Am[r * LDA + cc] + Am[cc * LDA + r]);
+    }
+    if (bad && tid == 0) *c.bad = 1.0;
+}
+
+// panel of the double step: Y2_J = [B_Jk B_J,k+1] P2 for every block row J outside the pivot block (two tiles per J)
+__global__ __launch_bounds__(256) void jq_panel2(JArgs A, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y, J = blockIdx.x;
+    const Ws w = carve(A, mission);
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
+    const int nblk = c.nblk;
+    if (!c.active || J >= nblk || J == k || J == k + 1 || k + 1 >= nblk) return;
+    const bool tr = J < k;
+    const double* Z0 = c.src + (tr ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
+    const double* Z1 = c.src + (tr ? (size_t)(k + 1) * nblk + J : (size_t)J * nblk + k + 1) * JTT;
+    const double *P00 = c.P2, *P10 = c.P2 + JTT, *P11 = c.P2 + 2 * JTT;
+    double* Y0 = c.Y + (size_t)J * 2 * JTT;
+    double* Y1 = Y0 + JTT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    d4 z0[4], z1[4];
+    load_frag(Z0, 16 * wave, tr, li, lg, z0);
+    load_frag(Z1, 16 * wave, tr, li, lg, z1);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        d4 pf[4];
+        d4 a0 = d4{0, 0, 0, 0}, a1 = d4{0, 0, 0, 0};
+        load_frag(P00, 16 * tj, false, li, lg, pf);  // Z0 P00 (symmetric)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0[ch][q], pf[ch][q], a0, 0, 0, 0);
+        load_frag(P10, 16 * tj, true, li, lg, pf);  // Z1 P10: the operand's rows are P10's columns
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1[ch][q], pf[ch][q], a0, 0, 0, 0);
+        load_frag(P10, 16 * tj, false, li, lg, pf);  // Z0 P01 = Z0 P10'
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z0[ch][q], pf[ch][q], a1, 0, 0, 0);
+        load_frag(P11, 16 * tj, false, li, lg, pf);  // Z1 P11 (symmetric)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(z1[ch][q], pf[ch][q], a1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Y0[(size_t)(16 * wave + lg + 4 * r) * JT + 16 * tj + li] = a0[r];
+            Y1[(size_t)(16 * wave + lg + 4 * r) * JT + 16 * tj + li] = a1[r];
+        }
+    }
+}
+
+// update of the double step: every tile (I, J), I >= J, of the lower triangle
+//   pivot block <- -P2      (I, k + h) <- Y2_I[h]      (k + h, J) <- Y2_J[h]'      else  B_IJ - Y2_I[0] B_Jk' - Y2_I[1] B_J,k+1'
+// (the last pass writes -(...) = the inverse itself, with both triangles)
+__global__ __launch_bounds__(256, 3) void jq_update2_bulk(JArgs A, int s, int mid, int k) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.z, chain = blockIdx.y;
+    const Ws w = carve(A, mission);
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
+    const int nblk = c.nblk;
+    if (!c.active || k + 1 >= nblk || (int)blockIdx.x >= nblk * (nblk + 1) / 2) return;
+    int I = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    if (I * (I + 1) / 2 > (int)blockIdx.x) I--;
+    if ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
+    const int J = blockIdx.x - I * (I + 1) / 2;
+    const bool last = k + 1 == nblk - 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    double* out = c.dst + ((size_t)I * nblk + J) * JTT;
+    double* outT = c.dst + ((size_t)J * nblk + I) * JTT;
+    const double sgn = last ? -1.0 : 1.0;
+    const bool Ik = I == k || I == k + 1, Jk = J == k || J == k + 1;
+    if (Ik || Jk) {
+        const double* src;
+        bool tr = false;
+        double f = sgn;
+        if (Ik && Jk)
+            src = c.P2 + (size_t)(I == k ? 0 : (J == k ? 1 : 2)) * JTT, f = -sgn;
+        else if (Jk)
+            src = c.Y + ((size_t)I * 2 + (J - k)) * JTT;
+        else
+            src = c.Y + ((size_t)J * 2 + (I - k)) * JTT, tr = true;
+        for (int i = tid; i < JTT; i += 256) {
+            const int r = i >> 6, cc = i & 63;
+            const double v = f * (tr ? src[(size_t)cc * JT + r] : src[i]);
+            out[i] = v;
+            if (last && I != J) outT[(size_t)cc * JT + r] = v;
+        }
+        return;
+    }
+    const bool trJ = J < k;
+    const double* Ct = c.src + ((size_t)I * nblk + J) * JTT;
+    double cv[2][2][4];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[ti][tj][r] = Ct[(size_t)(32 * wr + 16 * ti + lg + 4 * r) * JT + 32 * wc + 16 * tj + li];
+    d4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double* Zt = c.src + (trJ ? (size_t)(k + h) * nblk + J : (size_t)J * nblk + k + h) * JTT;
+        const double* Yt = c.Y + ((size_t)I * 2 + h) * JTT;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            d4 yf[2], zf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                yf[t] = *reinterpret_cast<const d4*>(Yt + (size_t)(32 * wr + 16 * t + li) * JT + 16 * ch + 4 * lg);
+                if (!trJ) {
+                    zf[t] = *reinterpret_cast<const d4*>(Zt + (size_t)(32 * wc + 16 * t + li) * JT + 16 * ch + 4 * lg);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zf[t][q] = Zt[(size_t)(16 * ch + 4 * lg + q) * JT + 32 * wc + 16 * t + li];
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[ti][q], zf[tj][q], acc[ti][tj], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = sgn * (cv[ti][tj][r] - acc[ti][tj][r]);
+                const int rr = 32 * wr + 16 * ti + lg + 4 * r, cc = 32 * wc + 16 * tj + li;
+                out[(size_t)rr * JT + cc] = v;
+                if (last && I != J) outT[(size_t)cc * JT + rr] = v;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // substitutions with the stored inverses.  mode 0 forward (w_j = S_j^-1 (r_j - C w_prev)), 1 middle (x_m = S_m^-1 (r_m - C w_l -
 // C' w_r)), 2 backward (x_j = w_j - S_j^-1 C' x_next).  The solution replaces rhs.  One workgroup per 16-row slab.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1458,11 +1706,13 @@ __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const
         const Chain ch = chain_step(d, chain, s, mid != 0);
         c.active = ch.active && w.st[ST_STATE] == 0.0 && w.st[ST_RETRY] == 0.0 && w.st[ST_GO] == 0.0;
         c.nblk = d.nblk;
-        const int p0 = d.nblk & 1;
-        c.src = sweep_buf(w, d, A.L, chain, ch.jj, (k + p0) & 1);
-        c.dst = sweep_buf(w, d, A.L, chain, ch.jj, (k + p0 + 1) & 1);
+        // pass t of np: a double step takes the pivots (2 t, 2 t + 1), an odd order ends with a single step
+        const int t = A.sweep2 ? (k >> 1) : k, p0 = sweep_parity0(A, d.nblk);
+        c.src = sweep_buf(w, d, A.L, chain, ch.jj, (t + p0) & 1);
+        c.dst = sweep_buf(w, d, A.L, chain, ch.jj, (t + p0 + 1) & 1);
         c.Pk = w.P + ((size_t)chain * 2 + (k & 1)) * JTT, c.Pn = w.P + ((size_t)chain * 2 + ((k + 1) & 1)) * JTT;
-        c.Y = w.Y + (size_t)chain * A.L.nblkS * JTT;
+        c.P2 = w.P + (size_t)(4 + 3 * chain) * JTT;
+        c.Y = w.Y + (size_t)chain * 2 * A.L.nblkS * JTT;
     } else {
         const Pol p = pol_carve(A, blockIdx.z);
         c.nblk = p.cnt[PC_NBLK];
@@ -1472,6 +1722,7 @@ __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const
         c.dst = ((k + p0 + 1) & 1) ? p.W1 : p.W0;
         c.Pk = p.P + (size_t)(k & 1) * JTT, c.Pn = p.P + (size_t)((k + 1) & 1) * JTT;
         c.Y = p.Y;
+        c.P2 = nullptr;
         c.G = p.G;
     }
     return c;
@@ -1525,7 +1776,11 @@ __global__ void jq_count(JArgs A) {
     const Ws w = carve(A, mission);
     if (threadIdx.x != 0 || w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const JDims d = jdims(A.S.N, A.S.Mk[mission]);
-    const double nb = d.nblk, per_knot = nb * ((nb - 1) * nb / 2 + (nb - 1)) * 2.0 * JT * JT * JT;
+    const double nb = d.nblk;
+    double tiles = nb * ((nb - 1) * nb / 2 + (nb - 1));  // 64^3 tile products per knot: update tiles + panel tiles of every pass
+    if (A.sweep2)  // double passes: two products per update tile outside the pivot block, four per panel block row; an odd order ends with a single pass
+        tiles = (double)(d.nblk / 2) * ((nb - 2) * (nb - 1) + 4 * (nb - 2)) + ((d.nblk & 1) ? (nb - 1) * nb / 2 + (nb - 1) : 0.0);
+    const double per_knot = tiles * 2.0 * JT * JT * JT;
     w.st[ST_FLOPS] += d.nj * per_knot + 2.0 * (2.0 * d.nj - 1.0) * 2.0 * (double)d.nkp * d.nkp;
 }
 
@@ -1556,7 +1811,7 @@ JLayout jq_layout(int N, int MS) {
     for (int p = 0; p < 2; ++p) L.o_bs[p] = take(6 * ncp), L.o_bz[p] = take(6 * ncp), L.o_ps[p] = take(nrow), L.o_pz[p] = take(nrow);
     L.o_pwgt = take(nrow);
     L.o_acc = take((size_t)d.nch * 12 * ncp);
-    L.o_Y = take((size_t)2 * d.nblk * JTT), L.o_P = take((size_t)4 * JTT);
+    L.o_Y = take((size_t)4 * d.nblk * JTT), L.o_P = take((size_t)10 * JTT);  // (per chain: two panel tiles per block row; 2 + 2 single pivots, 3 + 3 tiles of double pivots)
     L.o_scr = take((size_t)2 * d.nkp * d.nkp);
     const PolLayout PL = pol_layout(N, MS);
     L.o_inv = take(std::max((size_t)d.nj * d.nkp * d.nkp, PL.big_total));  // (the polish's matrices overlay the inverses: jqp_polish.inc pol_layout)
@@ -1662,10 +1917,31 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // two schedules of the sweep: look-ahead (the workgroup that updates the next pivot tile inverts it: one dependent launch less per
     // step -- a lone mission is bound by that chain) / bulk (thousands of tiles per launch: a leaner update kernel at three workgroups per
     // CU, the pivot inverse in a launch of its own)
-    const bool bulk = sched ? sched == 2 : K >= 8 && (size_t)K * 2 * ntri >= 1024;
+    const bool bulk = sched ? sched >= 2 : K >= 8 && (size_t)K * 2 * ntri >= 1024;
+    // ... schedule 3: the bulk schedule with TWO pivot tiles per pass over the matrix (jq_pivot2 / jq_panel2 / jq_update2_bulk: the update is
+    // bound by HBM, and a pass reads and writes the whole lower triangle).  Opt-in: measured at 64 agents (9 tiles per knot) the update
+    // kernels' time falls by 28 % but the pivot block's serial chain and the panel's doubled arithmetic take most of it back (+3.5 % at 200
+    // resident missions, nothing at 50, a lone mission LOSES 25-30 %): DESIGN.md 3.5
+    A.sweep2 = sched == 3 && nblk >= 2 ? 1 : 0;
+    const size_t lds_pivot2 = (size_t)3 * JT * LDA * sizeof(double);
+    if (A.sweep2 && hipFuncSetAttribute((const void*)jq_pivot2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pivot2) != hipSuccess) return RBP_ERR_HIP;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : 2;
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
+        if (A.sweep2) {
+            for (int k = 0; k + 1 < nblk; k += 2) {
+                JQ_LAUNCH(jq_pivot2, dim3(1, nchain, K), lds_pivot2, A, sidx, mid, k);
+                if (nblk > 2) JQ_LAUNCH(jq_panel2, dim3(nblk, nchain, K), 0, A, sidx, mid, k);
+                JQ_LAUNCH(jq_update2_bulk, dim3(ntri, nchain, K), 0, A, sidx, mid, k);
+            }
+            if (nblk & 1) {
+                const int k = nblk - 1;
+                JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, k);
+                JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, 0, sidx, mid, k);
+                JQ_LAUNCH(jq_update_bulk, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
+            }
+            return;
+        }
         JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, 0);
         for (int k = 0; k < nblk; ++k) {
             if (bulk && k > 0) JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, k);

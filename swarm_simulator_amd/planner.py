@@ -145,7 +145,7 @@ def last_error():
 
 def solver_opts(**kw):
     """rbp_solver_opts (include/rbp.h) with the library's defaults, fields overridden by keyword: polish, joint_wide_min_agents,
-    joint_corrector, joint_schedule (0 auto / 1 look-ahead / 2 bulk), qp_schedule (0 auto / 1 one workgroup per mission / 2 phase split),
+    joint_corrector, joint_schedule (0 auto / 1 look-ahead / 2 bulk / 3 bulk with two pivot tiles per pass), qp_schedule (0 auto / 1 one workgroup per mission / 2 phase split),
     qp_variant (0 / 2 / 4), qp_block_order, qp_groups, qp_rounds, qp_far_slack (metres; <= 0: off).  The library reads no environment variables: these are the switches."""
     o = A.rbp_solver_opts()
     lib().rbp_solver_opts_defaults(C.byref(o))

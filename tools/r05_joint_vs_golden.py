@@ -1,5 +1,5 @@
 """Developer tool (GPU box): the grid-wide joint solver against committed oracle vectors, case by case.
-usage: python tools/r05_joint_vs_golden.py <npz> [<npz> ...]     (joint64_sweep.npz | joint32_sweep.npz | joint_heldout.npz)"""
+usage: python tools/r05_joint_vs_golden.py [--schedule=N] <npz> [<npz> ...]     (joint64_sweep.npz | joint32_sweep.npz | joint_heldout.npz)"""
 import hashlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,8 @@ from tests import oracle_lib as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 p = Param.test_sweep(sequential=False)
-for name in sys.argv[1:]:
+SCHED = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--schedule=")), 0)
+for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
     gold = np.load(os.path.join(GOLDEN, name))
     n = len(gold["cost"])
     if "mission" in gold.files:
@@ -30,7 +31,7 @@ for name in sys.argv[1:]:
         worlds = [host.load_world(cases[i][1], p) for i in idx]
         inits = [host.ecbs_plan(w, m, p) for w, m in zip(worlds, missions)]
         plans = [g.clone_inputs() for g in inits]
-        sess = planner.Session(worlds, missions, p, plans)
+        sess = planner.Session(worlds, missions, p, plans, opts=planner.solver_opts(joint_schedule=SCHED))
         t = time.time(); sess.run(A.RBP_STAGE_ALL); st = sess.download(); dt = time.time() - t
         sess.close()
         agents = [int(a) for a in gold["agents"]] if "agents" in gold.files else [0, N // 3, (2 * N) // 3, N - 1]
