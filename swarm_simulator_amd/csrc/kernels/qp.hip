@@ -1608,7 +1608,6 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             const bool fwd = s < SF;
             const int jb = wave == 0 ? left_j(s) : right_j(s);
             if (jb >= 0) {
-                const int dir = wave == 0 ? +1 : -1;  // direction of this chain's elimination
                 const kl_lds* Mst = (const kl_lds*)(buf + (wave == 0 ? 0 : SCH));
                 kl_lds *A = (kl_lds*)small + KS_VPAD + (wave == 0 ? 0 : 3 * KS_VLEN), *Z = A + KS_VLEN, *V = A + 2 * KS_VLEN;
                 kl_lds* ps = (kl_lds*)small + 6 * KS_VLEN + (wave == 0 ? 0 : 64);
