@@ -400,6 +400,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the RBP path has no CPU fallback)")
+    if args.backend != "nccl":   # (functional test of the launcher / of a rank pair on a one-GPU box: ranks share devices; timings then mean nothing)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 
     from swarm_simulator_amd import planner
@@ -611,10 +613,12 @@ def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):
     init = host.ecbs_plan(w, m, param)
     dev = torch.device("cuda", local_rank)
 
+    xstats = {}
+
     def step():
         pr = init.clone_inputs()
         t0 = time.perf_counter()
-        ok, err = sharded.plan_sharded(w, m, param, pr, dist, dev)
+        ok, err = sharded.plan_sharded_device(w, m, param, pr, dist, dev, stats=xstats)
         torch.cuda.synchronize()
         return ok, err, time.perf_counter() - t0, pr
 
@@ -633,7 +637,7 @@ def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):
         dist.barrier()
     secs = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        t = torch.tensor([secs], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
     if rank == 0:
@@ -644,9 +648,15 @@ def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):
             "data": "256-agent mission derived from the reference's 64-agent pattern (tools/make_mission_256.py; no such file upstream), worlds/map1.bt",
             "config": {"workload": f"ONE {m.qn}-agent mission (M={pr.M}), Corridor::update sharded by agent over {n_ranks} rank(s) + one fused "
                                    f"all-gather, " + ("RBPPlanner JOINT QP (plan/sequential=false: knot blocks of order 9 N, grid-wide solver "
-                                                      "kernels/jqp.hip), replicated on every rank" if args.joint else
+                                                      "kernels/jqp.hip), " + (f"its twisted knot elimination shared by PAIRS of ranks (rank 2k the lower chain, "
+                                                      f"2k+1 the upper one; {xstats.get('exchanges', 0)} exchanges, {xstats.get('exchange_bytes', 0) / 1e6:.0f} MB each "
+                                                      "way per solve), sweeps / polish replicated" if xstats.get("exchanges") else "replicated on every rank")
+                                                      if args.joint else
                                                       f"RBPPlanner sweep sequential batch_size={args.batch_size}") + "; host buffers in and out",
-                       "agents": m.qn, "segments": pr.M, "parallelism": f"agents sharded over {n_ranks} GPU(s) (corridor), planner per rank",
+                       "agents": m.qn, "segments": pr.M, "parallelism": f"agents sharded over {n_ranks} GPU(s) (corridor), " +
+                       ("joint factorisation shared by rank pairs" if xstats.get("exchanges") else "planner per rank"),
+                       "backend": "single process" if dist is None else dist.get_backend(),
+                       "joint_exchanges_per_solve": xstats.get("exchanges", 0), "joint_exchange_bytes_per_solve": xstats.get("exchange_bytes", 0),
                        "qp_iterations": pr.qp_iterations,
                        "baseline_config": "c4", "qp_unpolished": pr.qp_unpolished, "kkt_max": pr.kkt_max, "all_missions_ok": bool(ok)}}))
     if dist is not None:

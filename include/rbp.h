@@ -33,7 +33,8 @@ enum {
     RBP_ERR_UNSUPPORTED_DEGREE = 11,   /* rbp_planner.hpp:344-346, 375-377: only n=5, phi=3 */
     RBP_ERR_BAD_ARGUMENT = 20,
     RBP_ERR_NO_DEVICE = 30,            /* HIP device / kernel image unavailable: the product path never falls back to CPU */
-    RBP_ERR_HIP = 31
+    RBP_ERR_HIP = 31,
+    RBP_ERR_EXCHANGE = 32              /* rbp_session_shard_joint: the caller's exchange hook reported a failure */
 };
 
 /* ---- distance map: what DynamicEDTOctomap(maxDist=1, tree, bbxMin, bbxMax, false) serves -------
@@ -198,6 +199,19 @@ int rbp_session_run(rbp_session* s, int stages, void* stream);
  * ordered after the solve.  For every other session rbp_session_run_async is rbp_session_run. */
 int rbp_session_run_async(rbp_session* s, int stages, void* stream);
 int rbp_session_wait(rbp_session* s);
+/* ---- ONE joint QP on TWO GPUs (ABI 5; BASELINE.json config 4 "agents sharded across GPUs") -------------------------
+ * The pair rows of the joint QP couple every agent with every other (rbp_planner.hpp:638-684), so the QP does not split by agent; what
+ * splits is its Newton system, block tridiagonal over the knots: the grid-wide solver eliminates it from both ends towards the middle
+ * knot (two chains), and the factorisation is ~85 % of a 256-agent mission.  After this call the session is rank `rank` of a pair of
+ * identical sessions (same missions, same options, one per GPU / process): rank 0 eliminates and substitutes along the lower chain, rank 1
+ * along the upper one, both assemble the middle knot; row sweeps, control and polish are replicated and bit-identical, so both ranks
+ * end with the SAME bits as an unsharded run.  Three kinds of exchange per interior-point iteration go through the caller's hook
+ * (the library owns send_dev / recv_dev, in HBM; the session's stream is synchronised before the hook is called; the hook returns 0 once the
+ * peer's `bytes` are in recv_dev, e.g. an all-gather over RCCL / xGMI -- swarm_simulator_amd/sharded.py): the explicit inverse of each
+ * chain's last knot (81 N^2 doubles rounded up to 64-wide tiles: 42 MB at 256 agents), and two vectors per Newton solve.  The hook is
+ * called on the thread that calls rbp_session_run; rbp_session_run_async is refused for a sharded session.  nranks must be 2 (1 = undo). */
+typedef int (*rbp_exchange_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes);
+int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user);
 /* solver options of this session (default: the context's, else rbp_solver_opts_defaults).  The QP workspace is reserved by the first
  * PLANNER run, for the options then in force: a session that only runs the CORRIDOR stage reserves none. */
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o);
@@ -283,8 +297,8 @@ void rbp_release_thread_context(void);
 /* library/version/diagnostics.  RBP_ABI_VERSION changes whenever a struct of this header changes its layout; a binding built
  * against another header must refuse to run (rbp_plan / rbp_counters are written by the library).  rbp_sizeof lets a binding
  * that cannot see this header (ctypes, cgo) compare its own struct sizes with the library's. */
-#define RBP_ABI_VERSION 4  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: contexts, device views;
-                              4: rbp_solver_opts (the library no longer reads environment variables) */
+#define RBP_ABI_VERSION 5  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: contexts, device views;
+                              4: rbp_solver_opts (the library no longer reads environment variables); 5: rbp_session_shard_joint, RBP_ERR_EXCHANGE */
 enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4, RBP_SIZEOF_DEVICE_ARRAYS = 5,
        RBP_SIZEOF_SOLVER_OPTS = 6 };
 int rbp_abi_version(void);

@@ -27,8 +27,9 @@ RBP_ERR_UNSUPPORTED_DEGREE = 11
 RBP_ERR_BAD_ARGUMENT = 20
 RBP_ERR_NO_DEVICE = 30
 RBP_ERR_HIP = 31
+RBP_ERR_EXCHANGE = 32
 
-RBP_ABI_VERSION = 4  # include/rbp.h
+RBP_ABI_VERSION = 5  # include/rbp.h
 
 RBP_STAGE_CORRIDOR = 1
 RBP_STAGE_PLANNER = 2

@@ -110,6 +110,10 @@ struct rbp_session {
     int worker_rc = RBP_OK;
     hipStream_t jstream = nullptr;
     hipEvent_t jev_in = nullptr;
+    // rbp_session_shard_joint: this session is one rank of a pair that shares a joint solve's factorisation (kernels/jqp.h JointShard);
+    // the exchange buffers are the session's own
+    JointShard shard{};
+    char* shard_buf = nullptr;
 };
 
 // waits for the session's asynchronous joint run, if one is in flight; reports its error once
@@ -543,6 +547,8 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
         int rc = launch_corridor(s->d, st);
         if (rc) return rc;
     }
+    if ((stages & RBP_STAGE_PLANNER) && s->shard.nranks == 2 && !s->joint_wide)
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: this plan does not run on the grid-wide joint solver (rbp_solver_opts.joint_wide_min_agents), there is no factorisation to share");
     if ((stages & RBP_STAGE_PLANNER) && s->joint_wide) {
         // grid-wide joint QP: a launch per phase; the host learns once per interior-point iteration whether any mission is still
         // running, so this call SYNCHRONISES the stream (unlike the batch path, which only enqueues)
@@ -550,6 +556,10 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
         int rc = RBP_OK;
         JointOpts jo;
         jo.corrector = o.joint_corrector ? 1 : 0, jo.schedule = o.joint_schedule;
+        if (s->shard.nranks == 2) {
+            if (async) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_run_async: a session sharded over two ranks (rbp_session_shard_joint) calls the exchange hook on the caller's thread: use rbp_session_run");
+            jo.shard = &s->shard;
+        }
         if (async) {
             // rbp_session_run_async: the host loop moves to a thread and a stream of the session's own, ordered after what the caller's
             // stream holds so far (inputs, the CORRIDOR stage, the prologue) by an event
@@ -574,7 +584,7 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
             return RBP_OK;
         }
         if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats, jo);
-        if (rc) return fail(rc, "joint QP: HIP error");
+        if (rc) return fail(rc, rc == RBP_ERR_EXCHANGE ? "joint QP: the exchange hook of rbp_session_shard_joint reported a failure" : "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
     } else if ((stages & RBP_STAGE_PLANNER) && o.qp_schedule == 2) {
         // phase split (kernels/qp_phase.inc): chip-wide row sweeps, one workgroup per mission for the chains; the missions are spread over a
@@ -610,6 +620,29 @@ int rbp_session_run_async(rbp_session* s, int stages, void* stream) { return run
 int rbp_session_wait(rbp_session* s) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     return join_worker(s);
+}
+
+int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user) {
+    if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
+    if (int jrc = join_worker(s)) return jrc;
+    if (nranks == 1) {  // undo: this session runs both chains again (the buffers stay until destroy)
+        s->shard.nranks = 1, s->shard.rank = 0, s->shard.exchange = nullptr, s->shard.user = nullptr;
+        return RBP_OK;
+    }
+    if (nranks != 2 || rank < 0 || rank > 1 || !exchange)
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: the twisted elimination has two chains -- nranks must be 2 (or 1 to undo), rank 0 or 1, and an exchange hook is needed");
+    if (s->param.sequential || s->d.N < 2)
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: only a joint QP (plan/sequential = false) has a factorisation to share; the sequential schedule shards by mission");
+    const size_t cap = joint_exchange_bytes(s->d.N, s->d.M, s->d.K);
+    if (!s->shard_buf) {
+        HIP_TRY(hipSetDevice(s->device));
+        const hipError_t e = hipMalloc((void**)&s->shard_buf, 2 * cap);
+        if (e != hipSuccess)
+            return fail(RBP_ERR_HIP, "rbp_session_shard_joint: exchange buffers (2 x " + std::to_string(cap) + " bytes) could not be reserved: " + hipGetErrorString(e));
+    }
+    s->shard.rank = rank, s->shard.nranks = 2, s->shard.send = (double*)s->shard_buf, s->shard.recv = (double*)(s->shard_buf + cap), s->shard.cap = cap;
+    s->shard.exchange = exchange, s->shard.user = user;
+    return RBP_OK;
 }
 
 int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream) {
@@ -761,6 +794,10 @@ void rbp_session_destroy(rbp_session* s) {
     if (s->ws_own) {
         (void)hipSetDevice(s->device);
         (void)hipFree(s->ws_own);
+    }
+    if (s->shard_buf) {
+        (void)hipSetDevice(s->device);
+        (void)hipFree(s->shard_buf);
     }
     if (s->ctx) {
         s->ctx->busy = false;  // the arena (and the QP workspace) stay with the context

@@ -23,6 +23,8 @@ struct JArgs {
     int ref_gate;   // substitution launches of a refinement pass: missions with ST_NREF < ref_gate are skipped
     int trace;      // RBP_JOINT_TRACE: device-side diagnostics of the polish's acceptance test
     int gond_only;  // launches of the centrality corrector: only missions with ST_GACT set take part
+    int chain0;     // first chain of a launch over the twisted elimination's chains (chain = blockIdx.y + chain0): 0, or the rank's own chain
+                    // when the factorisation is sharded over two ranks (JointShard)
     int sweep2;     // tile sweep of the knots (kind 0): 1 = two pivot tiles per pass (jq_pivot2 / jq_panel2 / jq_update2_bulk), 0 = one
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;
@@ -41,9 +43,24 @@ struct JointStats {
     int polish_rounds;  // active-set rounds of the polish
 };
 
+// A joint solve whose twisted knot elimination is spread over TWO ranks (BASELINE config 4; rbp_session_shard_joint of include/rbp.h):
+// rank r eliminates chain r and substitutes along it; everything else (row sweeps, control, polish, the middle knot) is replicated
+// and bit-identical on both ranks.  Three exchanges move data between the ranks (jq_xfer packs / unpacks per mission):
+// the explicit inverse of each chain's last knot before the middle knot is assembled, the forward vector of that knot before the middle
+// solve, and the chain's half of the solution after the backward pass.
+struct JointShard {
+    int rank = 0, nranks = 1;
+    double *send = nullptr, *recv = nullptr;  // device buffers of `cap` bytes each (the session's)
+    size_t cap = 0;
+    int (*exchange)(void* user, void* send_dev, void* recv_dev, size_t bytes) = nullptr;  // returns 0 when the peer's bytes are in recv
+    void* user = nullptr;
+};
+size_t joint_exchange_bytes(int N, int MS, int K);  // capacity the send / recv buffers of a K-mission session need
+
 struct JointOpts {  // what rbp_solver_opts says about the grid-wide joint solver
     int corrector = 1;  // one centrality corrector per interior-point iteration
     int schedule = 0;   // tile sweep: 0 automatic, 1 look-ahead, 2 bulk, 3 bulk with two pivot tiles per pass (opt-in)
+    const JointShard* shard = nullptr;  // two-rank factorisation (nullptr or nranks == 1: this rank runs both chains)
 };
 
 JLayout jq_layout(int N, int MS);

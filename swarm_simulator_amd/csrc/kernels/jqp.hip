@@ -894,7 +894,7 @@ __device__ __forceinline__ SweepCtx sweep_ctx(const JArgs& A, const Ws& w, const
 // T_jj + Schur updates, written into the first sweep buffer (tiles I >= J).  One thread per 3x3 block (Ai, Bi) = ((a, k), (b, l)).
 __global__ __launch_bounds__(256) void jq_prep(JArgs A, int s, int mid) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const int N = S.N, M = S.Mk[mission], MS = S.M;
@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void store_pivot_inverse(const double* Am, double* Pg
 // kernel has no look-ahead (jq_update_bulk)
 __global__ __launch_bounds__(256) void jq_pivot0(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void load_frag(const double* tile, int row0, bool tr,
 // panel of step k: Y_J = B_Jk P for every J != k  (B_Jk = tile (J, k) below the pivot, tile (k, J)' left of it)
 __global__ __launch_bounds__(256) void jq_panel(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y, J = blockIdx.x;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0, J = blockIdx.x;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void jq_panel(JArgs A, int kind, int s, int mi
 // The last step writes -(...) = the inverse itself, with both triangles.  Look-ahead: the workgroup of tile (k+1, k+1) inverts it.
 __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
 // operands of ONE 16-column chunk at a time and a register budget for three workgroups per CU.
 __global__ __launch_bounds__(256, 3) void jq_update_bulk(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256, 3) void jq_update_bulk(JArgs A, int kind, int 
 // P11 = Ps, P10 = -Ps W, P00 = Pa + W' Ps W.  The four 64^3 products run on plain FMAs out of LDS (a few microseconds per knot and pass).
 __global__ __launch_bounds__(256) void jq_pivot2(JArgs A, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y, tid = threadIdx.x;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0, tid = threadIdx.x;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(256) void jq_pivot2(JArgs A, int s, int mid, int k)
 // panel of the double step: Y2_J = [B_Jk B_J,k+1] P2 for every block row J outside the pivot block (two tiles per J)
 __global__ __launch_bounds__(256) void jq_panel2(JArgs A, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y, J = blockIdx.x;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0, J = blockIdx.x;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(256) void jq_panel2(JArgs A, int s, int mid, int k)
 // (the last pass writes -(...) = the inverse itself, with both triangles)
 __global__ __launch_bounds__(256, 3) void jq_update2_bulk(JArgs A, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, 0, s, mid, k, chain);
@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(256, 3) void jq_update2_bulk(JArgs A, int s, int mi
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y, tid = threadIdx.x;
+    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0, tid = threadIdx.x;
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     const JDims d = jdims(S.N, S.Mk[mission]);
@@ -1691,6 +1691,45 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
             w.wv[(size_t)jj * nkp + row] = acc;  // (copied to rhs by the mode 3 launch)
         else
             w.rhs[(size_t)jj * nkp + row] = w.wv[(size_t)jj * nkp + row] - acc;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// two-rank factorisation (JointShard): what one rank's chain produces and the other rank needs, packed per mission into a contiguous
+// buffer (dir 0, chain = this rank's) / scattered from the peer's buffer (dir 1, chain = the peer's).  what 0: the explicit inverse
+// of the chain's last knot (nkp^2 doubles; jq_prep of the middle knot reads both neighbours'); 1: that knot's forward vector w (nkp;
+// the middle solve, jq_mv mode 1, reads both); 2: the chain's rows of the solution in rhs (slot = (njS / 2) nkp).  Bytes only --
+// nothing is added, so both ranks hold bit-identical vectors afterwards.  The gates are those of the kernels that produced the data.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jq_xfer(JArgs A, int what, int dir, int chain, double* buf) {
+    const DevSession& S = A.S;
+    const int mission = blockIdx.y;
+    const Ws w = carve(A, mission);
+    if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
+    if (what != 0) {
+        if (w.st[ST_NREF] < (double)A.ref_gate) return;
+        if (A.gond_only && w.st[ST_GACT] == 0.0) return;
+    }
+    const JDims d = jdims(S.N, S.Mk[mission]);
+    const int m = d.nj / 2, nsteps = chain == 0 ? m : d.nj - 1 - m;  // knots of this chain
+    if (nsteps <= 0) return;
+    const size_t nkp = d.nkp, nkp2 = nkp * nkp;
+    const int last = chain == 0 ? m - 1 : m + 1, first = chain == 0 ? 0 : m + 1;
+    double* dev;
+    size_t n, slot;
+    if (what == 0)
+        dev = w.inv + (size_t)last * A.L.nkpS * A.L.nkpS, n = nkp2, slot = (size_t)A.L.nkpS * A.L.nkpS;
+    else if (what == 1)
+        dev = w.wv + (size_t)last * nkp, n = nkp, slot = A.L.nkpS;
+    else
+        dev = w.rhs + (size_t)first * nkp, n = (size_t)nsteps * nkp, slot = (size_t)(A.L.njS / 2) * A.L.nkpS;
+    double* b = buf + (size_t)mission * slot;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (dir == 0)
+            b[i] = dev[i];
+        else
+            dev[i] = b[i];
     }
 }
 
@@ -1822,6 +1861,10 @@ JLayout jq_layout(int N, int MS) {
 }
 
 size_t joint_workspace_bytes(int N, int MS) { return jq_layout(N, MS).stride * sizeof(double); }
+size_t joint_exchange_bytes(int N, int MS, int K) {  // the largest of jq_xfer's three slots is the inverse
+    const JDims d = jdims(N, MS);
+    return (size_t)K * std::max((size_t)d.nkp * d.nkp, (size_t)(d.nj / 2 + 1) * d.nkp) * sizeof(double);
+}
 
 #define JQ_LAUNCH(kern, grid, lds, ...) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, __VA_ARGS__)
 
@@ -1833,6 +1876,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // Solver constants (what each one does: jqp.h JArgs).  They are compiled in: the library reads no environment variables
     // (rbp_solver_opts carries the switches a caller may set).  The developer build (-DRBP_DEV_KNOBS, `make dev`) lets experiments override
     // them from the environment (tools/joint_env_sweep.sh).
+    A.chain0 = 0;
     A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0, A.gond_only = 0;
     A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
     A.pol_lh_early = 60, A.pol_lh_final = 160;
@@ -1887,11 +1931,38 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     if ((size_t)dm.nkp * sizeof(double) > 160 * 1024) return RBP_ERR_BAD_ARGUMENT;
     if (hipFuncSetAttribute((const void*)jq_mv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dm.nkp * sizeof(double))) != hipSuccess) return RBP_ERR_HIP;
     int nref_round = 0;  // refinement steps per solve in this round (the largest any mission asked for; the kernels gate per mission)
+    // two-rank factorisation: this rank launches its own chain only (grid.y = 1, A.chain0 = rank) and trades the three pieces of jq_xfer
+    const JointShard* sh = opts.shard && opts.shard->nranks == 2 ? opts.shard : nullptr;
+    const int ychains = sh ? 1 : 2, my_chain = sh ? sh->rank : 0;
+    int xrc = RBP_OK;
+    if (sh && (!sh->exchange || !sh->send || !sh->recv || sh->cap < joint_exchange_bytes(N, s.M, K) || sh->rank < 0 || sh->rank > 1)) return RBP_ERR_BAD_ARGUMENT;
+    auto exchange = [&](int what) {
+        if (xrc != RBP_OK) return;
+        const size_t slot = what == 0 ? (size_t)dm.nkp * dm.nkp : what == 1 ? (size_t)dm.nkp : (size_t)(dm.nj / 2) * dm.nkp;
+        if (slot == 0) return;
+        const dim3 grid((unsigned)std::min<size_t>((slot + 255) / 256, 2048), K);
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send);
+        if (hipStreamSynchronize(st) != hipSuccess) {
+            xrc = RBP_ERR_HIP;
+            return;
+        }
+        if (sh->exchange(sh->user, sh->send, sh->recv, (size_t)K * slot * sizeof(double)) != 0) {
+            xrc = RBP_ERR_EXCHANGE;
+            return;
+        }
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv);
+    };
     auto substitute = [&](int which_out) {
-        for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 0, sidx);
+        A.chain0 = my_chain;
+        for (int sidx = 0; sidx < steps; ++sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, ychains, K), dm.nkp * sizeof(double), A, 0, sidx);
+        A.chain0 = 0;
+        if (sh) exchange(1);
         JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 1, 0);
         JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 1, K), dm.nkp * sizeof(double), A, 3, 0);
-        for (int sidx = steps - 1; sidx >= 0; --sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, 2, K), dm.nkp * sizeof(double), A, 2, sidx);
+        A.chain0 = my_chain;
+        for (int sidx = steps - 1; sidx >= 0; --sidx) JQ_LAUNCH(jq_mv, dim3(dm.nkp / 16, ychains, K), dm.nkp * sizeof(double), A, 2, sidx);
+        A.chain0 = 0;
+        if (sh) exchange(2);
     };
     auto solve = [&](int which_out) {
         if (nref_round > 0) JQ_LAUNCH(jq_refine, dim3(npost, K), 0, A, 0, which_out);
@@ -1926,7 +1997,12 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     const size_t lds_pivot2 = (size_t)3 * JT * LDA * sizeof(double);
     if (A.sweep2 && hipFuncSetAttribute((const void*)jq_pivot2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pivot2) != hipSuccess) return RBP_ERR_HIP;
     auto factor_knot = [&](int sidx, int mid) {
-        const int nchain = mid ? 1 : 2;
+        const int nchain = mid ? 1 : ychains;
+        A.chain0 = mid ? 0 : my_chain;
+        struct Reset {
+            int& c;
+            ~Reset() { c = 0; }
+        } reset{A.chain0};
         JQ_LAUNCH(jq_prep, dim3(nprep, nchain, K), 0, A, sidx, mid);
         if (A.sweep2) {
             for (int k = 0; k + 1 < nblk; k += 2) {
@@ -2098,8 +2174,10 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         }
         JQ_LAUNCH(jq_count, dim3(K), 0, A);
         for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
+        if (sh) exchange(0);
         factor_knot(0, 1);
         if (hipPeekAtLastError() != hipSuccess) return RBP_ERR_HIP;  // (a launch the device refuses must not pass for a QP that does not converge)
+        if (xrc != RBP_OK) return xrc;  // (the peer rank is gone or the exchange hook failed: nothing sensible can follow)
         solve(0);
         JQ_LAUNCH(jq_sweep<PASS_AFF>, dim3(nsw, K), 0, A);
         JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 2, 0);
@@ -2131,6 +2209,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             JQ_LAUNCH(jq_ctrl, dim3(K), 0, A, 4, 0);
         }
         A.retry_only = 0;
+        if (xrc != RBP_OK) return xrc;
     }
     JQ_LAUNCH(jq_finish, dim3(K), 0, A);
     if (stats) stats->rounds = iters, stats->polish_rounds = polish_rounds;

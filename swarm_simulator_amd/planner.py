@@ -25,7 +25,12 @@ ERROR_TEXT = {
     A.RBP_ERR_BAD_ARGUMENT: "bad argument",
     A.RBP_ERR_NO_DEVICE: "no HIP device (the RBP path has no CPU fallback)",
     A.RBP_ERR_HIP: "HIP runtime error",
+    A.RBP_ERR_EXCHANGE: "exchange between the two ranks of a sharded joint solve failed",
 }
+
+
+# rbp_exchange_fn of include/rbp.h: int (*)(void* user, void* send_dev, void* recv_dev, size_t bytes)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class RbpLibraryMissing(RuntimeError):
@@ -94,6 +99,7 @@ def lib():
         L.rbp_session_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rbp_session_run_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rbp_session_wait.argtypes = [C.c_void_p]
+        L.rbp_session_shard_joint.argtypes = [C.c_void_p, C.c_int32, C.c_int32, EXCHANGE_FN, C.c_void_p]
         L.rbp_session_download.argtypes = [C.c_void_p, P(A.rbp_plan), A.c_int32_p, C.c_void_p]
         L.rbp_session_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.rbp_session_counters.argtypes = [C.c_void_p, P(A.rbp_counters), C.c_void_p]
@@ -127,7 +133,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
-    "rbp_session_run", "rbp_session_run_async", "rbp_session_wait", "rbp_session_set_agent_range",
+    "rbp_session_run", "rbp_session_run_async", "rbp_session_wait", "rbp_session_shard_joint", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
     "rbp_session_device_arrays",
     "rbp_version", "rbp_abi_version", "rbp_sizeof", "rbp_release_thread_context",
@@ -277,7 +283,8 @@ class Session:
     def run(self, stages=A.RBP_STAGE_ALL, stream=None):
         rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))
         if rc:
-            raise RuntimeError(f"rbp_session_run rc={rc}: {last_error()}")
+            cause = getattr(self, "_xchg_error", None)
+            raise RuntimeError(f"rbp_session_run rc={rc}: {last_error()}" + (f" ({cause!r})" if cause is not None else ""))
 
     def run_async(self, stages=A.RBP_STAGE_ALL, stream=None):
         """`run` that returns at once for a grid-wide joint session too (the solve proceeds on a library thread; `wait`, `download`
@@ -290,6 +297,56 @@ class Session:
         rc = lib().rbp_session_wait(self._h)
         if rc:
             raise RuntimeError(f"rbp_session_wait rc={rc}: {last_error()}")
+
+    def shard_joint(self, dist, group=None):
+        """make this session one rank of a PAIR that shares a joint solve (include/rbp.h rbp_session_shard_joint): rank 0 of `group`
+        (default: the whole process group, which must have two ranks) eliminates the lower chain of the knots, rank 1 the upper one; the
+        three exchanges per interior-point iteration are all-gathers on the library's device buffers -- RCCL over xGMI under the "nccl"
+        backend, through host copies under "gloo" (tests: two ranks on one GPU).  dist=None undoes it."""
+        import torch
+        if dist is None:
+            rc = lib().rbp_session_shard_joint(self._h, 0, 1, EXCHANGE_FN(), None)
+            self._xchg = None
+            if rc:
+                raise RuntimeError(f"rbp_session_shard_joint rc={rc}: {last_error()}")
+            return
+        ws, rank = dist.get_world_size(group), dist.get_rank(group)
+        if ws != 2:
+            raise ValueError(f"a joint solve is shared by TWO ranks (the twisted elimination has two chains); the group has {ws}")
+        gloo = dist.get_backend(group) == "gloo"
+        sess = self
+        self._xchg_error = None
+
+        class _View:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+        def hook(user, send_ptr, recv_ptr, nbytes):
+            try:
+                n = nbytes // 8
+                send = torch.as_tensor(_View(send_ptr, n), device="cuda")
+                recv = torch.as_tensor(_View(recv_ptr, n), device="cuda")
+                if gloo:
+                    outs = [torch.empty(n, dtype=torch.float64) for _ in range(2)]
+                    dist.all_gather(outs, send.cpu(), group=group)
+                    recv.copy_(outs[1 - rank])
+                else:
+                    out = torch.empty(2 * n, dtype=torch.float64, device=send.device)
+                    dist.all_gather_into_tensor(out, send, group=group)
+                    recv.copy_(out[(1 - rank) * n:(2 - rank) * n])
+                torch.cuda.synchronize()
+                sess.exchanges += 1
+                sess.exchange_bytes += nbytes
+                return 0
+            except BaseException as e:  # (an exception must not unwind through the C frames of the library)
+                sess._xchg_error = e
+                return 1
+
+        self.exchanges, self.exchange_bytes = 0, 0
+        self._xchg = EXCHANGE_FN(hook)  # (kept alive as long as the session may call it)
+        rc = lib().rbp_session_shard_joint(self._h, rank, 2, self._xchg, None)
+        if rc:
+            raise RuntimeError(f"rbp_session_shard_joint rc={rc}: {last_error()}")
 
     def set_agent_range(self, agent_begin: int, agent_end: int):
         rc = lib().rbp_session_set_agent_range(self._h, agent_begin, agent_end)

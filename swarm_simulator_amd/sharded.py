@@ -13,6 +13,13 @@ What shards, and what does not:
     further exchange is needed; scale-out of the QP comes from sharding MISSIONS (bench.py).  A Jacobi sweep over
     ranks would parallelise it but is a different algorithm with different answers (both agents of a frozen pair move
     at once, so the half-space rows no longer guarantee separation) and is deliberately not offered.
+  * RBPPlanner::update with plan/sequential = false (the reference's code default, param.hpp:67) is ONE joint QP over all agents whose
+    pair rows couple every agent with every other (rbp_planner.hpp:638-684): it does not split by agent either, but its Newton system
+    -- block tridiagonal over the knots, blocks of order 9 N -- does: the grid-wide solver eliminates it from both ends towards the
+    middle knot, and PAIRS of ranks share that factorisation (rank 2k the lower chain, rank 2k+1 the upper one; include/rbp.h
+    rbp_session_shard_joint, planner.Session.shard_joint).  Per interior-point iteration a pair trades the explicit inverse of each
+    chain's last knot (42 MB at 256 agents) and two vectors per Newton solve; every rank ends with the bits of the unsharded solve.
+    Two chains = two ranks per mission: with more ranks the pairs are replicas (or take different missions).
 """
 import numpy as np
 
@@ -134,7 +141,23 @@ def gather_corridor_device(dist, arrs, n_agents, slices):
             unpack_shard_device(arrs, out[r * maxb:r * maxb + lens[r]], slices[r], offs[r])
 
 
-def plan_sharded_device(world: World, mission: Mission, param: Param, plan: PlanResult, dist=None, device=None):
+_pair_groups = {}
+
+
+def pair_group(dist):
+    """the process group {2k, 2k+1} this rank shares a joint factorisation with (None: odd world size, or a single rank).  Created once
+    per world size -- every rank has to take part in the creation of every pair's group."""
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    if ws < 2 or ws % 2:
+        return None
+    if ws == 2:
+        return dist.group.WORLD
+    if ws not in _pair_groups:
+        _pair_groups[ws] = [dist.new_group([2 * k, 2 * k + 1]) for k in range(ws // 2)]
+    return _pair_groups[ws][rank // 2]
+
+
+def plan_sharded_device(world: World, mission: Mission, param: Param, plan: PlanResult, dist=None, device=None, stats=None):
     """plan_sharded with the mission RESIDENT in one session per rank: the CORRIDOR stage runs on the rank's agent slice, the shards are
     exchanged between the sessions' HBM arrays (gather_corridor_device), the PLANNER stage runs on the completed corridor -- nothing but
     the 4-byte ok flag crosses to the host between the two stages.  Returns (ok, error text)."""
@@ -161,7 +184,14 @@ def plan_sharded_device(world: World, mission: Mission, param: Param, plan: Plan
         if dist is not None and ws > 1:
             gather_corridor_device(dist, arrs, n, slices)
         sess.set_agent_range(0, n)
+        # a joint QP on the grid-wide solver: the ranks of a pair share its factorisation (module docstring)
+        if dist is not None and not param.sequential and n >= planner.solver_opts().joint_wide_min_agents > 0:
+            grp = pair_group(dist)
+            if grp is not None:
+                sess.shard_joint(dist, grp)
         sess.run(A.RBP_STAGE_PLANNER, stream)
+        if stats is not None:
+            stats["exchanges"], stats["exchange_bytes"] = getattr(sess, "exchanges", 0), getattr(sess, "exchange_bytes", 0)
         st = sess.download(stream)
         return st[0] == 0, ("" if st[0] == 0 else planner.ERROR_TEXT.get(st[0], str(st[0])))
     finally:

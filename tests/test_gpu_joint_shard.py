@@ -1,0 +1,218 @@
+"""ONE joint QP shared by TWO ranks (include/rbp.h rbp_session_shard_joint; BASELINE.json config 4).  Needs an MI355X.
+
+The joint QP's pair rows couple every agent with every other (rbp_planner.hpp:638-684); what splits is the twisted elimination of its
+block-tridiagonal Newton system: rank 0 takes the lower chain of knots, rank 1 the upper one, both assemble the middle knot, everything
+else is replicated.  The exchange moves bytes and adds nothing, so BOTH ranks must end with the bits of the unsharded solve:
+
+* two sessions in ONE process, one thread each, the exchange hook a rendezvous between the threads (no torch.distributed involved:
+  this isolates the library's side -- pack / hook / unpack, the chain offset of every factorisation and substitution launch);
+* several missions with different M in one sharded session (per-mission chain lengths, masked missions, polish requests that wait);
+* a real process group of two ranks on this one GPU (gloo: RCCL refuses two ranks on one device) through
+  swarm_simulator_amd.sharded.plan_sharded_device -- corridor sharded by agent, joint solve shared by the pair;
+* refusals: a sequential plan, three ranks, rbp_session_run_async on a sharded session; a failing hook ends `run` with RBP_ERR_EXCHANGE.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from swarm_simulator_amd import _abi as A
+from swarm_simulator_amd import host, planner
+from swarm_simulator_amd.types import Param
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, map_ids, mission_file=None, **pkw):
+    p = Param.test_sweep(sequential=False, **pkw)
+    m = host.load_mission(mission_file or f"mission_{n}agents_15.json")
+    worlds = [host.load_world(f"map{i}.bt", p) for i in map_ids]
+    inits = []
+    for w in worlds:
+        init = host.ecbs_plan(w, m, p)
+        assert planner.Corridor(w, m, p).update(False, init)
+        inits.append(init)
+    return p, m, worlds, inits
+
+
+class _Pair:
+    """the exchange between two sessions of one process: each hook posts its send pointer, waits for the peer's, copies device to device"""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.barrier = threading.Barrier(2, timeout=120)
+        self.posted = [None, None]
+        self.calls = [0, 0]
+        self.bytes = [0, 0]
+        self.hooks = [planner.EXCHANGE_FN(self._make(r)) for r in range(2)]
+
+    def _make(self, rank):
+        torch = self.torch
+
+        class _View:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+        def hook(user, send_ptr, recv_ptr, nbytes):
+            try:
+                self.posted[rank] = (send_ptr, nbytes)
+                self.barrier.wait()
+                peer_ptr, peer_bytes = self.posted[1 - rank]
+                if peer_bytes != nbytes:
+                    return 2
+                n = nbytes // 8
+                torch.as_tensor(_View(recv_ptr, n), device="cuda").copy_(torch.as_tensor(_View(peer_ptr, n), device="cuda"))
+                torch.cuda.synchronize()
+                self.barrier.wait()  # (the peer has read my send buffer before the library reuses it)
+                self.calls[rank] += 1
+                self.bytes[rank] += nbytes
+                return 0
+            except BaseException:
+                return 1
+        return hook
+
+
+def _run_pair(p, m, worlds, inits, **opts):
+    """the same missions in two sessions sharing every joint solve; returns (plans of rank 0, plans of rank 1, pair)"""
+    pair = _Pair()
+    plans = [[i.clone() for i in inits] for _ in range(2)]
+    o = planner.solver_opts(**opts) if opts else None
+    sessions = [planner.Session(worlds, [m] * len(worlds), p, plans[r], opts=o) for r in range(2)]
+    for r, s in enumerate(sessions):
+        rc = planner.lib().rbp_session_shard_joint(s._h, r, 2, pair.hooks[r], None)
+        assert rc == 0, planner.last_error()
+    errs = [None, None]
+
+    def work(r):
+        try:
+            sessions[r].run(A.RBP_STAGE_PLANNER)
+        except BaseException as e:
+            errs[r] = e
+            pair.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert errs == [None, None], errs
+    sts = [s.download() for s in sessions]
+    [s.close() for s in sessions]
+    assert sts[0] == [0] * len(worlds) and sts[1] == sts[0]
+    return plans[0], plans[1], pair
+
+
+def _run_alone(p, m, worlds, inits, **opts):
+    plans = [i.clone() for i in inits]
+    s = planner.Session(worlds, [m] * len(worlds), p, plans, opts=planner.solver_opts(**opts) if opts else None)
+    s.run(A.RBP_STAGE_PLANNER)
+    assert s.download() == [0] * len(worlds)
+    s.close()
+    return plans
+
+
+def _same_bits(a, b):
+    return (np.array_equal(a.ctrl.view(np.uint64), b.ctrl.view(np.uint64)) and np.array_equal(a.coef.view(np.uint64), b.coef.view(np.uint64))
+            and a.total_cost == b.total_cost and a.qp_iterations == b.qp_iterations and a.qp_unpolished == b.qp_unpolished and a.kkt_max == b.kkt_max)
+
+
+@pytest.mark.parametrize("n,map_id", [(16, 3), (32, 7), (64, 1)])
+def test_two_ranks_share_one_joint_solve_bit_for_bit(n, map_id):
+    p, m, worlds, inits = _inputs(n, [map_id])
+    alone = _run_alone(p, m, worlds, inits)
+    r0, r1, pair = _run_pair(p, m, worlds, inits)
+    assert alone[0].qp_unpolished == 0
+    assert _same_bits(r0[0], alone[0]) and _same_bits(r1[0], alone[0])
+    # one inverse per factorisation and two vectors per substitution pass went each way
+    nkp = (9 * n + 63) // 64 * 64
+    assert pair.calls[0] == pair.calls[1] > 3 * alone[0].qp_iterations
+    assert pair.bytes[0] == pair.bytes[1] >= alone[0].qp_iterations * nkp * nkp * 8
+
+
+def test_sharded_session_of_missions_with_different_m():
+    """four maps with their own M in one session: per-mission chain lengths and middle knots, missions that finish early are masked,
+    polish requests wait for company -- and the bulk schedule of the tile sweep (forced) on top of the chain offset"""
+    p, m, worlds, inits = _inputs(16, [3, 1, 2, 12])   # M = 34, 36, 35, 34: odd and even knot counts, chains of unequal length
+    assert len({i.M for i in inits}) > 1
+    for opts in ({}, {"joint_schedule": 2}):
+        alone = _run_alone(p, m, worlds, inits, **opts)
+        r0, r1, _ = _run_pair(p, m, worlds, inits, **opts)
+        for k in range(len(worlds)):
+            assert _same_bits(r0[k], alone[k]) and _same_bits(r1[k], alone[k]), (opts, k)
+
+
+def test_shard_joint_refusals_and_a_failing_hook():
+    L = planner.lib()
+    p, m, worlds, inits = _inputs(16, [3])
+    ok_hook = planner.EXCHANGE_FN(lambda u, s, r, n: 0)
+    bad_hook = planner.EXCHANGE_FN(lambda u, s, r, n: 7)
+    # a sequential plan has no joint factorisation
+    ps = Param.test_sweep()
+    s = planner.Session(worlds, [m], ps, [inits[0].clone()])
+    assert L.rbp_session_shard_joint(s._h, 0, 2, ok_hook, None) == A.RBP_ERR_BAD_ARGUMENT and b"sequential" in L.rbp_last_error()
+    s.close()
+    s = planner.Session(worlds, [m], p, [inits[0].clone()])
+    assert L.rbp_session_shard_joint(s._h, 0, 3, ok_hook, None) == A.RBP_ERR_BAD_ARGUMENT   # two chains: two ranks
+    assert L.rbp_session_shard_joint(s._h, 2, 2, ok_hook, None) == A.RBP_ERR_BAD_ARGUMENT
+    assert L.rbp_session_shard_joint(s._h, 0, 2, planner.EXCHANGE_FN(), None) == A.RBP_ERR_BAD_ARGUMENT
+    assert L.rbp_session_shard_joint(s._h, 1, 2, bad_hook, None) == 0
+    assert L.rbp_session_run_async(s._h, A.RBP_STAGE_PLANNER, None) == A.RBP_ERR_BAD_ARGUMENT
+    assert L.rbp_session_run(s._h, A.RBP_STAGE_PLANNER, None) == A.RBP_ERR_EXCHANGE and b"exchange hook" in L.rbp_last_error()
+    # undone: the session solves alone again, and gives the unsharded answer
+    assert L.rbp_session_shard_joint(s._h, 0, 1, planner.EXCHANGE_FN(), None) == 0
+    s.reset()
+    s.run(A.RBP_STAGE_PLANNER)
+    assert s.download() == [0]
+    alone = _run_alone(p, m, worlds, inits)
+    assert _same_bits(s.plans[0], alone[0])
+    s.close()
+    # fewer agents than the grid-wide solver takes: nothing to share, said so at run time
+    p8, m8, w8, i8 = _inputs(8, [5])
+    s = planner.Session(w8, [m8], p8, [i8[0].clone()])
+    assert L.rbp_session_shard_joint(s._h, 0, 2, ok_hook, None) == 0
+    assert L.rbp_session_run(s._h, A.RBP_STAGE_PLANNER, None) == A.RBP_ERR_BAD_ARGUMENT
+    s.close()
+
+
+def test_two_rank_process_group_shares_the_joint_solve(tmp_path):
+    """plan_sharded_device with plan/sequential = false under a real two-rank process group (gloo, both ranks on this GPU; on a multi-GPU
+    node the same code exchanges with all_gather_into_tensor over RCCL): Corridor::update sharded by agent, then the pair shares the joint
+    solve.  Every rank must return the unsharded plan bit for bit, and must have exchanged (not replicated)."""
+    import json, re, socket, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "s.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {root!r})
+        import numpy as np, torch
+        import torch.distributed as dist
+        from swarm_simulator_amd import host, planner
+        from swarm_simulator_amd.types import Param
+        from swarm_simulator_amd.sharded import plan_sharded_device
+        dist.init_process_group("gloo")
+        p = Param.test_sweep(sequential=False)
+        m = host.load_mission("mission_32agents_15.json")
+        w = host.load_world("map21.bt", p)
+        init = host.ecbs_plan(w, m, p)
+        full = init.clone_inputs()
+        assert planner.Corridor(w, m, p).update(False, full) and planner.RBPPlanner(m, p).update(False, full)
+        mine = init.clone_inputs()
+        stats = {{}}
+        ok, err = plan_sharded_device(w, m, p, mine, dist, "cuda:0", stats=stats)
+        same = bool(ok and np.array_equal(mine.sfc_box, full.sfc_box)
+                    and np.array_equal(mine.rsfc_normal.view(np.uint32), full.rsfc_normal.view(np.uint32))
+                    and np.array_equal(mine.ctrl.view(np.uint64), full.ctrl.view(np.uint64)) and mine.total_cost == full.total_cost
+                    and mine.qp_iterations == full.qp_iterations and mine.qp_unpolished == 0)
+        print(json.dumps({{"rank": dist.get_rank(), "same": same, "err": err, "exchanges": stats.get("exchanges", 0),
+                           "iterations": int(full.qp_iterations)}}))
+        dist.destroy_process_group()
+    """))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = str(sk.getsockname()[1]); sk.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [json.loads(t) for t in re.findall(r"\{[^{}]*\}", out.stdout)]
+    assert len(res) == 2 and all(r["same"] for r in res), res
+    assert all(r["exchanges"] > 3 * r["iterations"] for r in res), res
