@@ -129,3 +129,47 @@ def test_bench_gpus_flag_spawns_the_ranks():
                          capture_output=True, text=True, env=env1, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_four_rank_gloo_pair_groups(tmp_path):
+    """the rank pairs that share a joint factorisation (sharded.pair_group; rbp_session_shard_joint): with four ranks {0, 1} and {2, 3},
+    every rank taking part in the creation of every pair's group; an odd world has no pairs (the solve is then replicated)."""
+    script = tmp_path / "p.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        from swarm_simulator_amd.sharded import pair_group
+        dist.init_process_group("gloo")
+        r = dist.get_rank()
+        g = pair_group(dist)
+        assert pair_group(dist) is g                      # created once
+        t = torch.tensor([float(r)])
+        outs = [torch.zeros(1) for _ in range(2)]
+        dist.all_gather(outs, t, group=g)                 # the exchange pattern of planner.Session.shard_joint under gloo
+        print(json.dumps({{"rank": r, "group_rank": dist.get_rank(g), "size": dist.get_world_size(g), "members": [int(o.item()) for o in outs]}}))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+                          "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json, re
+    res = sorted((json.loads(t) for t in re.findall(r"\{[^{}]*\}", out.stdout)), key=lambda d: d["rank"])
+    assert [d["members"] for d in res] == [[0, 1], [0, 1], [2, 3], [2, 3]]
+    assert [d["group_rank"] for d in res] == [0, 1, 0, 1] and all(d["size"] == 2 for d in res)
+
+
+def test_pair_group_of_odd_and_single_worlds():
+    from swarm_simulator_amd.sharded import pair_group
+
+    class _D:
+        def __init__(self, ws, r):
+            self.ws, self.r = ws, r
+        def get_world_size(self):
+            return self.ws
+        def get_rank(self):
+            return self.r
+
+    assert pair_group(_D(1, 0)) is None and pair_group(_D(3, 2)) is None
