@@ -25,6 +25,7 @@ struct JArgs {
     int gond_only;  // launches of the centrality corrector: only missions with ST_GACT set take part
     int chain0;     // first chain of a launch over the twisted elimination's chains (chain = blockIdx.y + chain0): 0, or the rank's own chain
                     // when the factorisation is sharded over two ranks (JointShard)
+    int fuse_panel; // look-ahead schedule: jq_update forms the panel rows it needs itself (no jq_panel launch before it); set per launch
     int sweep2;     // tile sweep of the knots (kind 0): 1 = two pivot tiles per pass (jq_pivot2 / jq_panel2 / jq_update2_bulk), 0 = one
     int dreg_mode;  // 0: constant dual regularisation 1e-9 (qp.hip); 1: proximal, dreg = clamp(scale * mu, 1e-9, max)
     double dreg_scale, dreg_max;

@@ -993,10 +993,12 @@ constexpr int LDA = 66;  // (ds_read_b64 of lane (i, g) at row i, column 4 kk + 
 __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+constexpr size_t JQ_UPDATE_LDS_EXTRA = 64 * sizeof(double) + 16;  // thr[JT] + the bad-pivot flag behind Am and the scratch
 struct InvScratch {
     double Pi[4][16 * 18];  // per wave: its copy of the diagonal sub-tile, inverted in place
     double Yb[4][16 * 18];
-    double Zb[4][16 * 18];
+    // (Z of wave w lives in Pi[w]: a wave is done with its copy of the pivot sub-tile when it stores Z, only wave kk's copy is needed
+    // afterwards and wave kk stores no Z -- 9 KB less, which lets a third workgroup of jq_update onto a CU)
 };
 #define JQ_WSYNC()                                             \
     do {                                                       \
@@ -1049,7 +1051,7 @@ __device__ __forceinline__ bool gj16_lds(double* D, int lane, const double* thr 
     }
     return ok;
 }
-__device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* thr = nullptr) {
+__device__ __forceinline__ void inv64_lds_inl(double* Am, InvScratch* sc, int* bad, const double* thr = nullptr) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     for (int kk = 0; kk < 4; ++kk) {
         // every wave inverts its own copy of the diagonal sub-tile (no barrier between the inversion and the wave's panel product)
@@ -1071,7 +1073,7 @@ __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* th
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sc->Yb[wave][(lg + 4 * r) * 18 + li] = acc[r];
-                sc->Zb[wave][(lg + 4 * r) * 18 + li] = Am[(16 * wave + lg + 4 * r) * LDA + 16 * kk + li];
+                sc->Pi[wave][(lg + 4 * r) * 18 + li] = Am[(16 * wave + lg + 4 * r) * LDA + 16 * kk + li];
             }
         }
         __syncthreads();
@@ -1092,7 +1094,7 @@ __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* th
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double av = sc->Yb[wave][li * 18 + 4 * q + lg];
-                    const double bv = sc->Zb[jb][li * 18 + 4 * q + lg];
+                    const double bv = sc->Pi[jb][li * 18 + 4 * q + lg];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
 #pragma unroll
@@ -1102,6 +1104,9 @@ __device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* th
         __syncthreads();
     }
 }
+
+// (out of line for the pivot kernels, which have a CU to themselves; jq_update inlines it so that ITS register budget applies)
+__device__ void inv64_lds(double* Am, InvScratch* sc, int* bad, const double* thr = nullptr) { inv64_lds_inl(Am, sc, bad, thr); }
 
 // Pbuf[chain][parity] <- symmetrised inverse of the SPD tile held (as its NEGATED inverse after inv64_lds) in Am
 __device__ __forceinline__ void store_pivot_inverse(const double* Am, double* Pg) {
@@ -1183,31 +1188,71 @@ __global__ __launch_bounds__(256) void jq_panel(JArgs A, int kind, int s, int mi
     }
 }
 
+
+// Y_T = B_Tk P of step k (what jq_panel computes for row block T, the same instructions in the same order), written to LDS instead of
+// memory: when JArgs::fuse_panel is set every workgroup of jq_update forms the panel rows it needs itself and the panel launch -- a dependent
+// kernel boundary per 64 columns -- disappears from the look-ahead schedule (one extra 64^3 product per tile, P and B_Tk come from the L2).
+// Decided per launch (JArgs::fuse_panel): it pays while a launch is a round or so of workgroups (64 agents 0.267 -> 0.245 s; one chain of a
+// 256-agent mission, 666 tiles, 3.84 -> 3.75 s) and costs 5 % when both chains of that mission share the launches (1332 tiles).
+__device__ __forceinline__ void panel_rows_to_lds(const double* X, const double* P, int nblk, int k, int T, double* Am, int wave, int li, int lg) {
+    const bool tr = T < k;
+    const double* Z = X + (tr ? (size_t)k * nblk + T : (size_t)T * nblk + k) * JTT;
+    d4 zf[4];
+    load_frag(Z, 16 * wave, tr, li, lg, zf);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        d4 pf[4];
+        load_frag(P, 16 * tj, false, li, lg, pf);
+        d4 acc = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[ch][q], pf[ch][q], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Am[(16 * wave + lg + 4 * r) * LDA + 16 * tj + li] = acc[r];
+    }
+}
+
 // update of step k: every tile (I, J), I >= J, of the lower triangle
 //   (k, k) <- -P        (I, k) <- Y_I        (k, J) <- Y_J'        else  B_IJ - Y_I B_Jk'
 // The last step writes -(...) = the inverse itself, with both triangles.  Look-ahead: the workgroup of tile (k+1, k+1) inverts it.
-__global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int mid, int k) {
+__global__ __launch_bounds__(256, 3) void jq_update(JArgs A, int kind, int s, int mid, int k) {
     const DevSession& S = A.S;
-    const int mission = blockIdx.z, chain = blockIdx.y + A.chain0;
+    // Which tile this workgroup takes.  Workgroups start in the order x, then y: the chains of a launch are interleaved (so that both
+    // chains' first tiles start in the first round), and the tile that carries the look-ahead inversion -- 20 us of dependent work
+    // on top of its update, the longest job of the launch -- is taken by the FIRST workgroup of its chain instead of one in the middle of
+    // the triangle (with hundreds of tiles per chain, a 256-agent mission, it used to start in the second or third round and the
+    // launch ended with that inversion alone on the chip).  The arithmetic of a tile does not depend on who computes it.
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x), nchl = (int)gridDim.y;
+    const int mission = blockIdx.z, chain = lin % nchl + A.chain0;
+    int b = lin / nchl;
     const Ws w = carve(A, mission);
     const JDims d = jdims(S.N, S.Mk[mission]);
     const SweepCtx c = sweep_ctx(A, w, d, kind, s, mid, k, chain);
     const int nblk = c.nblk;
-    if (!c.active || (int)blockIdx.x >= nblk * (nblk + 1) / 2) return;
-    int I = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-    if (I * (I + 1) / 2 > (int)blockIdx.x) I--;
-    if ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
-    const int J = blockIdx.x - I * (I + 1) / 2;
+    if (!c.active || b >= nblk * (nblk + 1) / 2) return;
+    if (k + 1 < nblk) {
+        const int lookb = (k + 1) * (k + 2) / 2 + (k + 1);
+        b = b == 0 ? lookb : (b == lookb ? 0 : b);
+    }
+    int I = (int)((sqrtf(8.0f * b + 1.0f) - 1.0f) * 0.5f);
+    if (I * (I + 1) / 2 > b) I--;
+    if ((I + 1) * (I + 2) / 2 <= b) I++;
+    const int J = b - I * (I + 1) / 2;
     const double* X = c.src;
     double* Xn = c.dst;
     const double* P = c.Pk;
     const double* Yb = c.Y;
-    const bool last = k == nblk - 1, look = !last && I == k + 1 && J == k + 1;
+    const bool last = k == nblk - 1, look = !last && I == k + 1 && J == k + 1, fuse = A.fuse_panel != 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;  // this wave's 32 x 32 quadrant
-    __shared__ double Am[JT * LDA];
-    __shared__ InvScratch sc;
-    __shared__ int bad;
+    // LDS is DYNAMIC here (JQ_UPDATE_LDS bytes per launch): with a static size the compiler derives the occupancy from a 64 KB LDS and then
+    // spends 248 registers; the CU has 160 KB, three workgroups of 52.7 KB fit, and the register budget has to follow (launch bounds)
+    extern __shared__ double jq_update_lds[];
+    double* Am = jq_update_lds;                                        // [JT * LDA]
+    InvScratch& sc = *reinterpret_cast<InvScratch*>(Am + JT * LDA);
+    double* thr = reinterpret_cast<double*>(&sc + 1);                  // [JT]
+    int& bad = *reinterpret_cast<int*>(thr + JT);
     double* out = Xn + ((size_t)I * nblk + J) * JTT;
     double* outT = Xn + ((size_t)J * nblk + I) * JTT;
     const double sgn = last ? -1.0 : 1.0;
@@ -1215,7 +1260,10 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         const double* src = (I == k && J == k) ? P : (J == k ? Yb + (size_t)I * JTT : Yb + (size_t)J * JTT);
         const bool tr = (I == k && J != k);
         const double f = (I == k && J == k) ? -sgn : sgn;
-        for (int i = tid; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = src[i];
+        if (fuse && !(I == k && J == k))
+            panel_rows_to_lds(X, P, nblk, k, J == k ? I : J, Am, wave, li, lg);
+        else
+            for (int i = tid; i < JTT; i += 256) Am[(i >> 6) * LDA + (i & 63)] = src[i];
         __syncthreads();
         for (int i = tid; i < JTT; i += 256) {
             const int r = i >> 6, cc = i & 63;
@@ -1229,11 +1277,6 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
     const double* Zt = X + (trJ ? (size_t)k * nblk + J : (size_t)J * nblk + k) * JTT;
     const double* Yt = Yb + (size_t)I * JTT;
     const double* Ct = X + ((size_t)I * nblk + J) * JTT;
-    d4 yf[2][4], zf[2][4];
-    load_frag(Yt, 32 * wr, false, li, lg, yf[0]);
-    load_frag(Yt, 32 * wr + 16, false, li, lg, yf[1]);
-    load_frag(Zt, 32 * wc, trJ, li, lg, zf[0]);
-    load_frag(Zt, 32 * wc + 16, trJ, li, lg, zf[1]);
     double cv[2][2][4];
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -1241,18 +1284,49 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cv[ti][tj][r] = Ct[(size_t)(32 * wr + 16 * ti + lg + 4 * r) * JT + 32 * wc + 16 * tj + li];
+    if (fuse) {
+        panel_rows_to_lds(X, P, nblk, k, I, Am, wave, li, lg);
+        __syncthreads();
+    }
+    {
+        // operands of ONE 16-column chunk at a time (as jq_update_bulk): the register budget of three workgroups per CU
+        d4 acc[2][2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            d4 acc = d4{0, 0, 0, 0};
+            for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = d4{0, 0, 0, 0};
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+        for (int ch = 0; ch < 4; ++ch) {
+            d4 yf[2], zf[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[ti][ch][q], zf[tj][ch][q], acc, 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                if (fuse) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cv[ti][tj][r] = sgn * (cv[ti][tj][r] - acc[r]);
+                    for (int q = 0; q < 4; ++q) yf[t][q] = Am[(32 * wr + 16 * t + li) * LDA + 16 * ch + 4 * lg + q];
+                } else {
+                    yf[t] = *reinterpret_cast<const d4*>(Yt + (size_t)(32 * wr + 16 * t + li) * JT + 16 * ch + 4 * lg);
+                }
+                if (!trJ) {
+                    zf[t] = *reinterpret_cast<const d4*>(Zt + (size_t)(32 * wc + 16 * t + li) * JT + 16 * ch + 4 * lg);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) zf[t][q] = Zt[(size_t)(16 * ch + 4 * lg + q) * JT + 32 * wc + 16 * t + li];
+                }
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[ti][q], zf[tj][q], acc[ti][tj], 0, 0, 0);
         }
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cv[ti][tj][r] = sgn * (cv[ti][tj][r] - acc[ti][tj][r]);
+    }
     if (!(last && I != J) && !look) {
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -1263,6 +1337,7 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         return;
     }
     // through LDS: mirrored store of the last step / look-ahead inversion of the next pivot
+    if (fuse) __syncthreads();  // (Y_I is still being read from Am by the other waves)
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -1277,10 +1352,9 @@ __global__ __launch_bounds__(256) void jq_update(JArgs A, int kind, int s, int m
         if (last) outT[i] = Am[cc * LDA + r];
     }
     if (look) {
-        __shared__ double thr[JT];
         if (c.G && tid < JT) thr[tid] = A.pol_tau * w.st[ST_PTAU] * c.G[((size_t)(k + 1) * nblk + (k + 1)) * JTT + (size_t)tid * (JT + 1)];
         __syncthreads();
-        inv64_lds(Am, &sc, &bad, c.G ? thr : nullptr);
+        inv64_lds_inl(Am, &sc, &bad, c.G ? thr : nullptr);
         store_pivot_inverse(Am, c.Pn);
         if (bad && tid == 0) *c.bad = 1.0;
     }
@@ -1876,7 +1950,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // Solver constants (what each one does: jqp.h JArgs).  They are compiled in: the library reads no environment variables
     // (rbp_solver_opts carries the switches a caller may set).  The developer build (-DRBP_DEV_KNOBS, `make dev`) lets experiments override
     // them from the environment (tools/joint_env_sweep.sh).
-    A.chain0 = 0;
+    A.chain0 = 0, A.fuse_panel = 0;
     A.dreg_mode = 0, A.dreg_scale = 1.0, A.dreg_max = 1e-4, A.ref_step = 0, A.ref_gate = 0, A.retry_only = 0, A.gond_only = 0;
     A.tune[0] = JQ_MU0, A.tune[1] = JQ_SFLOOR, A.tune[2] = 3.0, A.tune[3] = JQ_NBHD_GAMMA, A.tune[4] = JQ_STEP_FRAC;
     A.pol_lh_early = 60, A.pol_lh_final = 160;
@@ -1995,6 +2069,14 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // resident missions, nothing at 50, a lone mission LOSES 25-30 %): DESIGN.md 3.5
     A.sweep2 = sched == 3 && nblk >= 2 ? 1 : 0;
     const size_t lds_pivot2 = (size_t)3 * JT * LDA * sizeof(double);
+    // jq_update takes its LDS dynamically (52.7 KB: three workgroups per CU).  Few tiles per launch (one chain of a lone mission: the launch is
+    // as long as the workgroup that carries the look-ahead inversion) run better with TWO workgroups per CU -- asked for by padding the
+    // request (measured, 256 agents: one chain per launch 3.76 s against 4.00 s; two chains, 1332 tiles, 4.40 against 4.27 the other way)
+    const size_t lds_update_min = (size_t)JT * LDA * sizeof(double) + sizeof(InvScratch) + JQ_UPDATE_LDS_EXTRA;
+    auto few_tiles = [&](int nchain) { return (size_t)K * nchain * ntri < 1024; };  // (about a round of workgroups per launch)
+    auto lds_update_for = [&](int nchain) { return few_tiles(nchain) ? (size_t)72 * 1024 : lds_update_min; };
+    const size_t lds_update = lds_update_min;  // (the polish's S_AA sweeps: one chain, usually few tiles -- but several missions at once)
+    if (hipFuncSetAttribute((const void*)jq_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(72 * 1024)) != hipSuccess) return RBP_ERR_HIP;
     if (A.sweep2 && hipFuncSetAttribute((const void*)jq_pivot2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pivot2) != hipSuccess) return RBP_ERR_HIP;
     auto factor_knot = [&](int sidx, int mid) {
         const int nchain = mid ? 1 : ychains;
@@ -2021,11 +2103,12 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, 0);
         for (int k = 0; k < nblk; ++k) {
             if (bulk && k > 0) JQ_LAUNCH(jq_pivot0, dim3(1, nchain, K), 0, A, 0, sidx, mid, k);
-            if (nblk > 1) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, 0, sidx, mid, k);
+            A.fuse_panel = !bulk && few_tiles(nchain) ? 1 : 0;
+            if (nblk > 1 && !A.fuse_panel) JQ_LAUNCH(jq_panel, dim3(nblk, nchain, K), 0, A, 0, sidx, mid, k);
             if (bulk)
                 JQ_LAUNCH(jq_update_bulk, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
             else
-                JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), 0, A, 0, sidx, mid, k);
+                JQ_LAUNCH(jq_update, dim3(ntri, nchain, K), lds_update_for(nchain), A, 0, sidx, mid, k);
         }
     };
     A.trace = trace ? 1 : 0;
@@ -2083,8 +2166,9 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                     JQ_LAUNCH(jp_gather, dim3(nblk_max * nblk_max, K), 0, A);
                     JQ_LAUNCH(jq_pivot0, dim3(1, 1, K), 0, A, 1, 0, 0, 0);
                     for (int k = 0; k < nblk_max; ++k) {
-                        if (nblk_max > 1) JQ_LAUNCH(jq_panel, dim3(nblk_max, 1, K), 0, A, 1, 0, 0, k);
-                        JQ_LAUNCH(jq_update, dim3(nblk_max * (nblk_max + 1) / 2, 1, K), 0, A, 1, 0, 0, k);
+                        A.fuse_panel = (size_t)K * nblk_max * (nblk_max + 1) / 2 < 1024 ? 1 : 0;
+                        if (nblk_max > 1 && !A.fuse_panel) JQ_LAUNCH(jq_panel, dim3(nblk_max, 1, K), 0, A, 1, 0, 0, k);
+                        JQ_LAUNCH(jq_update, dim3(nblk_max * (nblk_max + 1) / 2, 1, K), lds_update, A, 1, 0, 0, k);
                     }
                     JQ_LAUNCH(jp_z, dim3(nblk_max * 4, K), nblk_max * JT * sizeof(double), A, 0);
                     for (int rr = 0; rr < 2; ++rr) {  // two refinement steps: the multipliers' signs drive the exchange
