@@ -2062,7 +2062,10 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     // two schedules of the sweep: look-ahead (the workgroup that updates the next pivot tile inverts it: one dependent launch less per
     // step -- a lone mission is bound by that chain) / bulk (thousands of tiles per launch: a leaner update kernel at three workgroups per
     // CU, the pivot inverse in a launch of its own)
-    const bool bulk = sched ? sched >= 2 : K >= 8 && (size_t)K * 2 * ntri >= 1024;
+    // (round 5: since the look-ahead tile is taken by the first workgroup of its chain and jq_update runs three workgroups per CU, the
+    // look-ahead schedule is ahead at every resident-set size measured -- 64 agents: 50 missions 1721 against 1656, 200 missions 2278 against
+    // 2227 agent-trajectories/s, profiles/r05_joint_lookfirst_ab.txt -- so the automatic choice is look-ahead; bulk stays selectable)
+    const bool bulk = sched ? sched >= 2 : false;
     // ... schedule 3: the bulk schedule with TWO pivot tiles per pass over the matrix (jq_pivot2 / jq_panel2 / jq_update2_bulk: the update is
     // bound by HBM, and a pass reads and writes the whole lower triangle).  Opt-in: measured at 64 agents (9 tiles per knot) the update
     // kernels' time falls by 28 % but the pivot block's serial chain and the panel's doubled arithmetic take most of it back (+3.5 % at 200
