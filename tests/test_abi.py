@@ -135,3 +135,16 @@ def test_solver_opts_defaults_and_checks():
     assert planner.lib().rbp_session_set_solver_opts(None, C.byref(bad)) == A.RBP_ERR_BAD_ARGUMENT   # (null session)
     with pytest.raises(TypeError):
         planner.solver_opts(no_such_field=1)
+
+
+def test_shard_joint_entry_point_without_a_gpu():
+    """rbp_session_shard_joint (ABI 5) is exported with the hook type the binding declares; a null session is refused before any device
+    work (the sharing itself is a GPU test: tests/test_gpu_joint_shard.py), and the error code of a failing hook has its text"""
+    L = planner.lib()
+    hook = planner.EXCHANGE_FN(lambda user, send, recv, nbytes: 0)
+    assert L.rbp_session_shard_joint(None, 0, 2, hook, None) == A.RBP_ERR_BAD_ARGUMENT
+    assert b"null session" in L.rbp_last_error()
+    assert A.RBP_ERR_EXCHANGE == 32 and A.RBP_ERR_EXCHANGE in planner.ERROR_TEXT
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rbp.h")).read()
+    assert "typedef int (*rbp_exchange_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes);" in hdr
+    assert "RBP_ERR_EXCHANGE = 32" in hdr

@@ -1,4 +1,4 @@
-"""profiles/<tag>_joint_kernel.json: the rate of the joint solver's dominant kernel (jq_update_bulk) from a rocprofv3 kernel trace of
+"""profiles/<tag>_joint_kernel.json: the rate of the joint solver's dominant kernel (jq_update / jq_update_bulk) from a rocprofv3 kernel trace of
 `bench.py --joint --agents 64 --missions-per-gpu 200 --steps 1 --warmup 1` (two steps in the trace) and the flops the solver logs per step
 (the bench line of the same workload), tied to the joint solver's sources by hash (bench.py prints it only while the hash matches).
 
@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stats, benchlog, out = sys.argv[1:4]
 nblk, nj = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (9, 35)
 rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
-k = next(r for n, r in rows.items() if "jq_update_bulk" in n)
+# the update kernel of the schedule in force: jq_update (look-ahead, the automatic choice since round 5's lean kernel) or jq_update_bulk
+cands = [(float(r["TotalDurationNs"]), ("jq_update_bulk" if "jq_update_bulk" in n else "jq_update"), r) for n, r in rows.items()
+         if "jq_update_bulk(" in n or "jq_update(" in n]
+_, kname, k = max(cands, key=lambda c: c[0])
 line = [l for l in open(benchlog).read().splitlines() if l.startswith("{")][-1]
 b = json.loads(line)
 flops = b["roofline"]["flops_per_step"]
@@ -31,10 +34,11 @@ for f in sorted(os.listdir(base)):
         h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
 tflops = share * flops * 2 / secs / 1e12
 json.dump({"joint_source_sha": h.hexdigest()[:16], "missions_per_gpu": b["config"]["missions_per_gpu"], "agents": b["config"]["agents"],
-           "kernel": "jq_update_bulk", "launches": int(k["Calls"]), "kernel_seconds_two_steps": secs, "logged_flops_per_step": flops,
+           "kernel": kname, "launches": int(k["Calls"]), "kernel_seconds_two_steps": secs, "logged_flops_per_step": flops,
            "share_of_logged_flops_in_this_kernel": share,
            "share_derivation": f"tile counts of jq_count (kernels/jqp.hip): update tiles (nblk-1) nblk / 2 against panel tiles (nblk-1) per 64-column step, "
                                f"plus the substitutions' 2 (2 nj - 1) 2 nkp^2; nblk = {nblk}, nj = {nj}",
+           "kernel_time_includes": "the polish's S_AA sweeps (kind 1 launches of the same kernel), whose flops are NOT among the logged ones: the rate is a lower bound" if kname == "jq_update" else "the knots' sweeps only",
            "tflops": tflops, "frac_of_fp64_mfma_peak": tflops / 78.6,
            "note": "rocprofv3 --kernel-trace --stats of `bench.py --joint --agents 64 --missions-per-gpu 200 --steps 1 --warmup 1` (two steps in the "
                    "trace): the *_joint_kernel_stats.csv beside this file"}, open(out, "w"), indent=1)
