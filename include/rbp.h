@@ -249,7 +249,9 @@ int rbp_session_device_arrays(rbp_session* s, int32_t mission, rbp_device_arrays
 /* work counters of the last `run`, for the roofline report: see DESIGN.md */
 typedef struct rbp_counters {
     double sfc_samples;     /* getDistance-equivalent samples tested by the SFC kernel (summed over missions) */
-    double qp_flops;        /* flops of the dense block factorisations/solves the QP kernel executed */
+    double qp_flops;        /* flops of the dense block factorisations/solves the QP kernel executed (grid-wide joint solver: the
+                               ALGORITHMIC figure of the mission -- tile sweeps + substitutions -- whether or not panel rows are re-formed
+                               per tile, and on each rank of a pair that shares the solve) */
     double qp_ipm_iters;    /* interior-point iterations summed over QPs */
     double qp_solves;       /* number of batch QPs solved */
     double qp_constraint_rows; /* inequality rows swept (rows x passes) */
