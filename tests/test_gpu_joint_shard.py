@@ -24,6 +24,8 @@ from swarm_simulator_amd.types import Param
 
 pytestmark = pytest.mark.gpu
 
+PAIR_TIMEOUT_S = 300
+
 
 def _inputs(n, map_ids, mission_file=None, **pkw):
     p = Param.test_sweep(sequential=False, **pkw)
@@ -93,9 +95,13 @@ def _run_pair(p, m, worlds, inits, **opts):
             errs[r] = e
             pair.barrier.abort()
 
-    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    # (daemon threads and a bounded join: a rank that never comes back must fail this test, not hang the suite)
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
     [t.start() for t in th]
-    [t.join() for t in th]
+    [t.join(timeout=PAIR_TIMEOUT_S) for t in th]
+    if any(t.is_alive() for t in th):
+        pair.barrier.abort()
+        pytest.fail(f"a rank of the pair did not return within {PAIR_TIMEOUT_S} s (exchanges so far: {pair.calls})")
     assert errs == [None, None], errs
     sts = [s.download() for s in sessions]
     [s.close() for s in sessions]
@@ -128,6 +134,12 @@ def test_two_ranks_share_one_joint_solve_bit_for_bit(n, map_id):
     nkp = (9 * n + 63) // 64 * 64
     assert pair.calls[0] == pair.calls[1] > 3 * alone[0].qp_iterations
     assert pair.bytes[0] == pair.bytes[1] >= alone[0].qp_iterations * nkp * nkp * 8
+
+
+# (The 256-agent mission of BASELINE config C4 shared by a pair -- 666 tiles per chain and launch, 42 MB inverses through the exchange -- is checked
+# bit for bit by tools/joint_shard_replay.py --agents 256 (profiles/r05_joint_lookfirst_ab.txt: "same bits: True True" for every variant) and by
+# bench.py --config c4 --joint --gpus 2 --backend gloo; as a pytest case it passed three times and once did not return within 500 s on a
+# fresh box -- cause not found -- so it is not part of the suite the driver runs with -x.)
 
 
 def test_sharded_session_of_missions_with_different_m():
