@@ -260,7 +260,7 @@ class Session:
     def __init__(self, worlds, missions, param: Param, plans, device=0, opts=None):
         K = len(plans)
         assert len(worlds) == K and len(missions) == K
-        self.K, self.plans, self.param = K, plans, param
+        self.K, self.plans, self.param, self.device = K, plans, param, device
         self._keep = (worlds, missions)
         self._w = (A.rbp_world * K)(*[w.c_struct() for w in worlds])
         self._m = (A.rbp_mission * K)(*[m.c_struct() for m in missions])
@@ -315,6 +315,7 @@ class Session:
             raise ValueError(f"a joint solve is shared by TWO ranks (the twisted elimination has two chains); the group has {ws}")
         gloo = dist.get_backend(group) == "gloo"
         sess = self
+        dev = torch.device("cuda", self.device)
         self._xchg_error = None
 
         class _View:
@@ -324,8 +325,8 @@ class Session:
         def hook(user, send_ptr, recv_ptr, nbytes):
             try:
                 n = nbytes // 8
-                send = torch.as_tensor(_View(send_ptr, n), device="cuda")
-                recv = torch.as_tensor(_View(recv_ptr, n), device="cuda")
+                send = torch.as_tensor(_View(send_ptr, n), device=dev)   # (the library's buffers live on the session's device)
+                recv = torch.as_tensor(_View(recv_ptr, n), device=dev)
                 if gloo:
                     outs = [torch.empty(n, dtype=torch.float64) for _ in range(2)]
                     dist.all_gather(outs, send.cpu(), group=group)
@@ -334,7 +335,7 @@ class Session:
                     out = torch.empty(2 * n, dtype=torch.float64, device=send.device)
                     dist.all_gather_into_tensor(out, send, group=group)
                     recv.copy_(out[(1 - rank) * n:(2 - rank) * n])
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(dev)
                 sess.exchanges += 1
                 sess.exchange_bytes += nbytes
                 return 0
