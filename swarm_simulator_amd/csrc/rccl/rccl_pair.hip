@@ -1,0 +1,84 @@
+// rccl_pair.hip -- include/rbp_rccl.h: the exchange hook of a sharded joint solve (rbp_session_shard_joint) as RCCL send / recv over xGMI.
+// A library of its own (lib/librbp_rccl.so) so that the core library does not depend on RCCL.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+#include "rbp_rccl.h"
+
+static_assert(sizeof(ncclUniqueId) == RBP_RCCL_ID_BYTES, "RBP_RCCL_ID_BYTES must be sizeof(ncclUniqueId)");
+
+struct rbp_rccl_pair {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int device = 0, rank = 0, peer = 0;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::string& what) {
+    g_err = what;
+    return 1;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rbp_rccl_last_error(void) { return g_err.c_str(); }
+
+int rbp_rccl_unique_id(void* id_out) {
+    if (!id_out) return fail("rbp_rccl_unique_id: null buffer");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    std::memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int rbp_rccl_pair_create(rbp_rccl_pair** out, int device, int rank, int nranks, const void* id_bytes) {
+    if (!out || !id_bytes) return fail("rbp_rccl_pair_create: null argument");
+    if (!(nranks == 2 || nranks == 1) || rank < 0 || rank >= nranks) return fail("rbp_rccl_pair_create: a pair has two ranks (or one: the self-test), rank in range");
+    if (hipSetDevice(device) != hipSuccess) return fail("rbp_rccl_pair_create: hipSetDevice failed");
+    rbp_rccl_pair* p = new rbp_rccl_pair();
+    p->device = device, p->rank = rank, p->peer = nranks == 2 ? 1 - rank : rank;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&p->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        delete p;
+        return fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+        ncclCommDestroy(p->comm);
+        delete p;
+        return fail("rbp_rccl_pair_create: hipStreamCreate failed");
+    }
+    *out = p;
+    return 0;
+}
+
+int rbp_rccl_exchange(void* pair, void* send_dev, void* recv_dev, size_t bytes) {
+    rbp_rccl_pair* p = static_cast<rbp_rccl_pair*>(pair);
+    if (!p || !send_dev || !recv_dev) return fail("rbp_rccl_exchange: null argument");
+    if (bytes == 0) return 0;
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclSend(send_dev, bytes, ncclChar, p->peer, p->comm, p->stream);
+    if (r == ncclSuccess) r = ncclRecv(recv_dev, bytes, ncclChar, p->peer, p->comm, p->stream);
+    const ncclResult_t e = ncclGroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return fail(std::string("rbp_rccl_exchange: ") + ncclGetErrorString(r));
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return fail("rbp_rccl_exchange: stream synchronisation failed");
+    return 0;
+}
+
+void rbp_rccl_pair_destroy(rbp_rccl_pair* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->comm) (void)ncclCommDestroy(p->comm);
+    delete p;
+}
+
+}  // extern "C"

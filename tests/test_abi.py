@@ -148,3 +148,24 @@ def test_shard_joint_entry_point_without_a_gpu():
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rbp.h")).read()
     assert "typedef int (*rbp_exchange_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes);" in hdr
     assert "RBP_ERR_EXCHANGE = 32" in hdr
+
+
+def test_rccl_library_exports_every_symbol_of_rbp_rccl_h():
+    """lib/librbp_rccl.so (the RCCL exchange hook of a sharded joint solve; a library of its own so that the core does not link RCCL):
+    every function include/rbp_rccl.h declares is exported, and the hook has the signature of rbp_exchange_fn.  Checked with nm: loading it
+    here would bring a second HIP runtime into this process."""
+    import shutil, subprocess
+    so = os.path.join(A.LIB_DIR, "librbp_rccl.so")
+    if not os.path.exists(so):
+        pytest.skip("librbp_rccl.so not built (no RCCL headers where build() ran)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "rbp_rccl.h")).read()
+    declared = set(re.findall(r"\b(rbp_rccl_[a-z_]+)\s*\(", hdr.split("#ifdef __cplusplus")[1]))
+    assert declared == {"rbp_rccl_unique_id", "rbp_rccl_pair_create", "rbp_rccl_exchange", "rbp_rccl_pair_destroy", "rbp_rccl_last_error"}
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    syms = subprocess.run([nm, "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rbp_rccl_[a-z_]+)", syms))
+    assert declared <= exported, declared - exported
+    assert "int rbp_rccl_exchange(void* pair, void* send_dev, void* recv_dev, size_t bytes);" in hdr   # = rbp_exchange_fn of rbp.h
+    core = subprocess.run([nm, "-D", os.path.join(A.LIB_DIR, "librbp_hip.so")], capture_output=True, text=True).stdout
+    assert "nccl" not in core.lower()   # the core library stays free of RCCL
