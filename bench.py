@@ -13,7 +13,9 @@ Multi-GPU: missions are independent, so ranks take disjoint slices of the sweep 
 `--gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks.
 
 `--config c4` times ONE 256-agent mission whose Corridor::update is sharded by agent over the ranks (one fused RCCL
-all-gather) followed by the planner sweep (BASELINE.json config 4).
+all-gather) followed by the planner sweep (BASELINE.json config 4).  With `--joint` the mission is ONE joint QP on the grid-wide solver,
+and on an even number of ranks PAIRS of ranks share its knot elimination (rbp_session_shard_joint; swarm_simulator_amd/sharded.py) --
+`--gpus 2 --backend gloo` runs that pair on a one-GPU box as a correctness line (both ranks on the one device: its time means nothing).
 
 Prints ONE JSON line (rank 0).
 """
