@@ -78,7 +78,24 @@ typedef struct rbp_param {
     int32_t iteration;   /* plan/iteration 1 */
     int32_t time_scale;  /* plan/time_scale true */
     int32_t log;         /* log false */
+    int32_t timescale_rule; /* NOT a key of the reference (ABI 6): which candidate times timeScale's velocity check inspects -- see below */
 } rbp_param;
+
+/* rbp_param.timescale_rule.  scale_to_max_vel (rbp_planner.hpp:756-794) evaluates |velocity| at t = 0, t = dt and at the roots
+ * roots_derivative(2, coef_der) returns (:727-754): eigenvalues of the cubic's companion matrix from Eigen::EigenSolver, of which the loop
+ * `for (j = 0; j < i; j++)` (:746, i = 2 = the derivative order) reads only the FIRST TWO, in Eigen's internal order.
+ *   RBP_TIMESCALE_ALL_REAL_ROOTS (0, the default): every real root of the cubic is a candidate.  The factor can only be >= the reference's
+ *     (more candidates), is still a power of 1.1, and respects max_vel at EVERY velocity extremum -- the reference's literal rule can leave
+ *     a segment above max_vel when the skipped third eigenvalue holds the peak.  Independent of any eigenvalue ordering.
+ *   RBP_TIMESCALE_FIRST_EIGENVALUES (1): the loop as written -- the real ones among the first two eigenvalues, in the order of the real
+ *     Schur decomposition of Eigen 3.3.x (Francis double-shift QR on the companion matrix, eigenvalues read off T from the top), restated
+ *     from Eigen's published algorithm in kernels/qp.hip; Eigen is an un-pinned system dependency of the reference, so this order is a
+ *     documented, deterministic choice, not a pinned one.
+ * Both factors are always computed: rbp_plan.time_scale is the selected rule's (and what coef / T / corridor times are scaled by),
+ * rbp_plan.time_scale_alt the other rule's -- `time_scale != time_scale_alt` tells a caller that the two rules disagree on this plan
+ * (6 of 150 cases on the 50-map sweep with limits scaled by 1 / 0.5 / 0.25, each time by one step of the 1.1 ladder:
+ * tests/test_timescale_rule.py). */
+enum { RBP_TIMESCALE_ALL_REAL_ROOTS = 0, RBP_TIMESCALE_FIRST_EIGENVALUES = 1 };
 
 /* Fill `p` with the defaults of Param::setROSParam (param.hpp:44-70). */
 void rbp_param_defaults(rbp_param* p);
@@ -121,6 +138,7 @@ typedef struct rbp_plan {
     double kkt_max;         /* max over the batch QPs of the accepted answer's KKT residual: polished QPs max(row violation [m],
                                -min multiplier / max(1, max multiplier)); unpolished QPs max(primal residual [m], relative dual
                                residual, complementarity mu) */
+    double time_scale_alt;  /* (ABI 6) the factor the OTHER rule of rbp_param.timescale_rule gives for this plan; != time_scale: the rules disagree */
 } rbp_plan;
 
 /* ---- the two stage calls (synchronous; results on return) -------------------------------------
@@ -268,7 +286,7 @@ size_t rbp_session_workspace_bytes(rbp_session* s);
  * times its first plan, or wants the allocation failure before it has uploaded anything else */
 int rbp_session_reserve_workspace(rbp_session* s, void* stream);
 
-/* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 28 = SC_N (layout: kernels/rbp_dev.h SC_*) */
+/* raw per-mission diagnostic scalars of the last run: out[K][n], n <= 36 = SC_N (layout: kernels/rbp_dev.h SC_*) */
 int rbp_session_scalars(rbp_session* s, double* out, int n, void* stream);
 
 /* ---- contexts: device memory kept across calls -------------------------------------------------
@@ -299,8 +317,9 @@ void rbp_release_thread_context(void);
 /* library/version/diagnostics.  RBP_ABI_VERSION changes whenever a struct of this header changes its layout; a binding built
  * against another header must refuse to run (rbp_plan / rbp_counters are written by the library).  rbp_sizeof lets a binding
  * that cannot see this header (ctypes, cgo) compare its own struct sizes with the library's. */
-#define RBP_ABI_VERSION 5  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: contexts, device views;
-                              4: rbp_solver_opts (the library no longer reads environment variables); 5: rbp_session_shard_joint, RBP_ERR_EXCHANGE */
+#define RBP_ABI_VERSION 6  /* 1: round 1; 2: rbp_plan.qp_solves/qp_unpolished/kkt_max, rbp_counters.qp_row_bytes/kkt_max; 3: contexts, device views;
+                              4: rbp_solver_opts (the library no longer reads environment variables); 5: rbp_session_shard_joint, RBP_ERR_EXCHANGE;
+                              6: rbp_param.timescale_rule, rbp_plan.time_scale_alt */
 enum { RBP_SIZEOF_WORLD = 0, RBP_SIZEOF_MISSION = 1, RBP_SIZEOF_PARAM = 2, RBP_SIZEOF_PLAN = 3, RBP_SIZEOF_COUNTERS = 4, RBP_SIZEOF_DEVICE_ARRAYS = 5,
        RBP_SIZEOF_SOLVER_OPTS = 6 };
 int rbp_abi_version(void);

@@ -14,6 +14,7 @@
  */
 #include "rbp_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1271,7 +1272,239 @@ static int real_roots(const double* c, int deg, double* out) {
     return n;
 }
 
-double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan) { /* :209-266, :708-847 */
+
+/* ---- roots_derivative AS WRITTEN (:727-754): eigenvalues of the companion matrix, the first `i` of them ---------------------------
+ * The reference builds the companion matrix A of the stripped polynomial (:737-744: first row -c_{j+1}/c_0, ones on the subdiagonal),
+ * takes Eigen::EigenSolver<MatrixXd>(A).eigenvalues() and keeps the REAL ones among the first i = 2 entries (`j < i`, :746-751).  Which
+ * two of the three roots those are is decided by the order in which Eigen's real Schur decomposition deflates them.  Eigen is an
+ * un-vendored, un-pinned system dependency of the reference (CMakeLists.txt:21 `EIGEN3_INCLUDE_DIR`); what is restated here is its
+ * PUBLISHED algorithm as of Eigen 3.3.x (the release line of Ubuntu 18.04 / ROS Melodic, 3.3.4): RealSchur<MatrixType>::compute =
+ * scale by the largest |entry|, Hessenberg reduction (the identity on a companion matrix: its Householder vectors have zero tails),
+ * computeFromHessenberg = Francis double-shift QR sweeps with deflation test |T(k,k-1)| <= eps (|T(k-1,k-1)| + |T(k,k)|), Wilkinson's /
+ * MATLAB's exceptional shifts at local iterations 10 / 30, splitOffTwoRows for 2 x 2 blocks (a block with real eigenvalues is rotated
+ * to upper triangular form), then EigenSolver reads the eigenvalues off the quasi-triangular T from the top (EigenSolver::compute).
+ * Arithmetic of the Householder / Givens applications is written out in the order of Eigen's Householder.h / Jacobi.h; last-bit
+ * differences to a particular Eigen build (vectorisation, FMA) cannot be excluded and do not matter: only the ORDER of well separated
+ * roots and their values to ~1e-15 enter timeScale.  Guarded where the reference reads out of bounds: with fewer than i eigenvalues
+ * (n_der < 2) it indexes past the end of es.eigenvalues() (:747); here the loop stops at n_der.
+ * PARITY UNPINNED against a real Eigen (absent); pinned against an independent numpy restatement of the same published algorithm
+ * (tests/golden/make_kkt_reference.py, tests/test_timescale_rule.py). */
+static void es_householder(const double* v, int n, double* ess, double* tau, double* beta) { /* Householder.h makeHouseholder */
+    double tail = 0;
+    for (int i = 1; i < n; ++i) tail += v[i] * v[i];
+    const double c0 = v[0];
+    if (tail <= DBL_MIN) {
+        *tau = 0, *beta = c0;
+        for (int i = 1; i < n; ++i) ess[i - 1] = 0;
+    } else {
+        double b = sqrt(c0 * c0 + tail);
+        if (c0 >= 0) b = -b;
+        for (int i = 1; i < n; ++i) ess[i - 1] = v[i] / (c0 - b);
+        *tau = (b - c0) / b, *beta = b;
+    }
+}
+static void es_house_left(double T[3][3], int r0, int nr, int c0, int c1, const double* ess, double tau) { /* applyHouseholderOnTheLeft */
+    if (nr == 1) {
+        for (int j = c0; j <= c1; ++j) T[r0][j] *= (1 - tau);
+    } else if (tau != 0) {
+        for (int j = c0; j <= c1; ++j) {
+            double tmp = 0;
+            for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * T[r0 + i][j];
+            tmp += T[r0][j];
+            T[r0][j] -= tau * tmp;
+            for (int i = 1; i < nr; ++i) T[r0 + i][j] -= tau * ess[i - 1] * tmp;
+        }
+    }
+}
+static void es_house_right(double T[3][3], int r0, int r1, int c0, int nc, const double* ess, double tau) { /* applyHouseholderOnTheRight */
+    if (nc == 1) {
+        for (int i = r0; i <= r1; ++i) T[i][c0] *= (1 - tau);
+    } else if (tau != 0) {
+        for (int i = r0; i <= r1; ++i) {
+            double tmp = 0;
+            for (int j = 1; j < nc; ++j) tmp += T[i][c0 + j] * ess[j - 1];
+            tmp += T[i][c0];
+            T[i][c0] -= tau * tmp;
+            for (int j = 1; j < nc; ++j) T[i][c0 + j] -= tau * tmp * ess[j - 1];
+        }
+    }
+}
+/* eigenvalues of the n x n (n <= 3) upper Hessenberg matrix A in EigenSolver's order; returns 0 if the QR iteration did not converge */
+static int es_eigenvalues(double A[3][3], int n, double* re, double* im) {
+    double T[3][3], scale = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) scale = fmax(scale, fabs(A[i][j]));
+    if (scale < DBL_MIN) {
+        for (int i = 0; i < n; ++i) re[i] = 0, im[i] = 0;
+        return 1;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T[i][j] = A[i][j] / scale;
+    double norm = 0; /* computeNormOfT */
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < (j + 2 < n ? j + 2 : n); ++i) norm += fabs(T[i][j]);
+    int iu = n - 1, iter = 0, total = 0;
+    double exshift = 0;
+    if (norm != 0)
+        while (iu >= 0) {
+            int il = iu; /* findSmallSubdiagEntry */
+            while (il > 0) {
+                const double sd = fabs(T[il - 1][il - 1]) + fabs(T[il][il]);
+                if (fabs(T[il][il - 1]) <= DBL_EPSILON * sd) break;
+                il--;
+            }
+            if (il == iu) { /* one root */
+                T[iu][iu] += exshift;
+                if (iu > 0) T[iu][iu - 1] = 0;
+                iu--, iter = 0;
+            } else if (il == iu - 1) { /* splitOffTwoRows */
+                const double p = 0.5 * (T[iu - 1][iu - 1] - T[iu][iu]);
+                const double q = p * p + T[iu][iu - 1] * T[iu - 1][iu];
+                T[iu][iu] += exshift, T[iu - 1][iu - 1] += exshift;
+                if (q >= 0) {
+                    const double z = sqrt(fabs(q));
+                    const double gp = (p >= 0) ? p + z : p - z, gq = T[iu][iu - 1];
+                    double c, sn; /* JacobiRotation::makeGivens (real) */
+                    if (gq == 0) {
+                        c = gp < 0 ? -1 : 1, sn = 0;
+                    } else if (gp == 0) {
+                        c = 0, sn = gq < 0 ? 1 : -1;
+                    } else if (fabs(gp) > fabs(gq)) {
+                        const double t = gq / gp;
+                        double u = sqrt(1 + t * t);
+                        if (gp < 0) u = -u;
+                        c = 1 / u, sn = -t * c;
+                    } else {
+                        const double t = gp / gq;
+                        double u = sqrt(1 + t * t);
+                        if (gq < 0) u = -u;
+                        sn = -1 / u, c = -t * sn;
+                    }
+                    for (int j = iu - 1; j < n; ++j) { /* rightCols(size-iu+1).applyOnTheLeft(iu-1, iu, rot.adjoint()) */
+                        const double x = T[iu - 1][j], y = T[iu][j];
+                        T[iu - 1][j] = c * x - sn * y, T[iu][j] = sn * x + c * y;
+                    }
+                    for (int i = 0; i <= iu; ++i) { /* topRows(iu+1).applyOnTheRight(iu-1, iu, rot) */
+                        const double x = T[i][iu - 1], y = T[i][iu];
+                        T[i][iu - 1] = c * x - sn * y, T[i][iu] = sn * x + c * y;
+                    }
+                    T[iu][iu - 1] = 0;
+                }
+                if (iu > 1) T[iu - 1][iu - 2] = 0;
+                iu -= 2, iter = 0;
+            } else { /* il < iu - 1: only n = 3, il = 0, iu = 2 */
+                double sh0 = T[iu][iu], sh1 = T[iu - 1][iu - 1], sh2 = T[iu][iu - 1] * T[iu - 1][iu]; /* computeShift */
+                if (iter == 10) {
+                    exshift += sh0;
+                    for (int i = 0; i <= iu; ++i) T[i][i] -= sh0;
+                    const double sd = fabs(T[iu][iu - 1]) + fabs(T[iu - 1][iu - 2]);
+                    sh0 = 0.75 * sd, sh1 = 0.75 * sd, sh2 = -0.4375 * sd * sd;
+                }
+                if (iter == 30) {
+                    double sd = (sh1 - sh0) / 2.0;
+                    sd = sd * sd + sh2;
+                    if (sd > 0) {
+                        sd = sqrt(sd);
+                        if (sh1 < sh0) sd = -sd;
+                        sd = sd + (sh1 - sh0) / 2.0;
+                        sd = sh0 - sh2 / sd;
+                        exshift += sd;
+                        for (int i = 0; i <= iu; ++i) T[i][i] -= sd;
+                        sh0 = sh1 = sh2 = 0.964;
+                    }
+                }
+                iter++, total++;
+                if (total > 40 * n) return 0;
+                int imm; /* initFrancisQRStep */
+                double v[3] = {0, 0, 0};
+                for (imm = iu - 2; imm >= il; --imm) {
+                    const double Tmm = T[imm][imm], r = sh0 - Tmm, sd = sh1 - Tmm;
+                    v[0] = (r * sd - sh2) / T[imm + 1][imm] + T[imm][imm + 1];
+                    v[1] = T[imm + 1][imm + 1] - Tmm - r - sd;
+                    v[2] = T[imm + 2][imm + 1];
+                    if (imm == il) break;
+                    const double lhs = T[imm][imm - 1] * (fabs(v[1]) + fabs(v[2]));
+                    const double rhs = v[0] * (fabs(T[imm - 1][imm - 1]) + fabs(Tmm) + fabs(T[imm + 1][imm + 1]));
+                    if (fabs(lhs) < DBL_EPSILON * rhs) break;
+                }
+                for (int k = imm; k <= iu - 2; ++k) { /* performFrancisQRStep */
+                    const int first = (k == imm);
+                    double w[3], ess[2], tau, beta;
+                    if (first)
+                        w[0] = v[0], w[1] = v[1], w[2] = v[2];
+                    else
+                        w[0] = T[k][k - 1], w[1] = T[k + 1][k - 1], w[2] = T[k + 2][k - 1];
+                    es_householder(w, 3, ess, &tau, &beta);
+                    if (beta != 0) {
+                        if (first && k > il)
+                            T[k][k - 1] = -T[k][k - 1];
+                        else if (!first)
+                            T[k][k - 1] = beta;
+                        es_house_left(T, k, 3, k, n - 1, ess, tau);
+                        es_house_right(T, 0, (iu < k + 3 ? iu : k + 3), k, 3, ess, tau);
+                    }
+                }
+                {
+                    double w[2] = {T[iu - 1][iu - 2], T[iu][iu - 2]}, ess[1], tau, beta;
+                    es_householder(w, 2, ess, &tau, &beta);
+                    if (beta != 0) {
+                        T[iu - 1][iu - 2] = beta;
+                        es_house_left(T, iu - 1, 2, iu - 1, n - 1, ess, tau);
+                        es_house_right(T, 0, iu, iu - 1, 2, ess, tau);
+                    }
+                }
+                for (int i = imm + 2; i <= iu; ++i) { /* clean up pollution due to round-off errors */
+                    T[i][i - 2] = 0;
+                    if (i > imm + 2) T[i][i - 3] = 0;
+                }
+            }
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T[i][j] *= scale;
+    for (int i = 0; i < n; ++i) { /* EigenSolver::compute: eigenvalues from the quasi-triangular T, top to bottom */
+        if (i == n - 1 || T[i + 1][i] == 0) {
+            re[i] = T[i][i], im[i] = 0;
+        } else {
+            const double p = 0.5 * (T[i][i] - T[i + 1][i + 1]);
+            double t0 = T[i + 1][i], t1 = T[i][i + 1];
+            const double mx = fmax(fabs(p), fmax(fabs(t0), fabs(t1)));
+            t0 /= mx, t1 /= mx;
+            const double p0 = p / mx, z = mx * sqrt(fabs(p0 * p0 + t0 * t1));
+            re[i] = T[i + 1][i + 1] + p, im[i] = z;
+            re[i + 1] = T[i + 1][i + 1] + p, im[i + 1] = -z;
+            ++i;
+        }
+    }
+    return 1;
+}
+/* roots_derivative(i, coef_der) :727-754 for the polynomial c[0] t^deg + ... + c[deg] (row i of coef_der): the real ones among the first
+ * `take` eigenvalues (the reference passes the derivative order i = 2 as that bound, :746) */
+static int first_eigen_roots(const double* c, int deg, int take, double* out) {
+    while (deg > 0 && c[0] == 0) c++, deg--; /* :729-733 */
+    if (deg == 0) return 0;
+    double A[3][3] = {{0}}, re[3], im[3];
+    for (int j = 0; j < deg; ++j) { /* :737-744 */
+        if (j < deg - 1) A[j + 1][j] = 1;
+        A[0][j] = -c[j + 1] / c[0];
+    }
+    if (!es_eigenvalues(A, deg, re, im)) return 0;
+    int n = 0;
+    for (int j = 0; j < take && j < deg; ++j) /* :746-751 (guard: j < deg) */
+        if (im[j] == 0) out[n++] = re[j];
+    return n;
+}
+/* for the tests: eigenvalues in EigenSolver order of the companion matrix of c[0] t^deg + ... (deg <= 3, c[0] != 0) */
+int oracle_companion_eigenvalues(const double* c, int deg, double* re, double* im) {
+    if (deg < 1 || deg > 3 || c[0] == 0) return -1;
+    double A[3][3] = {{0}};
+    for (int j = 0; j < deg; ++j) {
+        if (j < deg - 1) A[j + 1][j] = 1;
+        A[0][j] = -c[j + 1] / c[0];
+    }
+    return es_eigenvalues(A, deg, re, im) ? deg : 0;
+}
+
+static double time_scale_by_rule(const rbp_mission* mission, const rbp_plan* plan, int rule) { /* :209-233, :708-847; rule: rbp_param.timescale_rule */
     const int N = plan->N, M = plan->M, n = 5;
     double time_scale = 1;
     for (int qi = 0; qi < N; ++qi)
@@ -1285,7 +1518,8 @@ double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan) { /* :209-2
                 /* scale_to_max_vel :756-794 */
                 {
                     double ts[8];
-                    int nt = real_roots(cd[2], 3, ts); /* roots of the 2nd derivative = velocity extrema */
+                    int nt = rule == RBP_TIMESCALE_FIRST_EIGENVALUES ? first_eigen_roots(cd[2], 3, 2, ts) /* roots_derivative(2, coef_der) :761 */
+                                                                     : real_roots(cd[2], 3, ts); /* every velocity extremum */
                     ts[nt++] = 0, ts[nt++] = dt;
                     double vel_max = 0, t_max = 0;
                     for (int a = 0; a < nt; ++a) {
@@ -1334,6 +1568,13 @@ double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan) { /* :209-2
                     if (time_scale < sc) time_scale = sc;
                 }
             }
+    return time_scale;
+}
+
+double oracle_time_scale_rule(const rbp_mission* mission, rbp_plan* plan, int rule) { /* :209-266 */
+    const int N = plan->N, M = plan->M, n = 5;
+    const double time_scale = time_scale_by_rule(mission, plan, rule);
+    plan->time_scale_alt = time_scale_by_rule(mission, plan, rule == RBP_TIMESCALE_FIRST_EIGENVALUES ? RBP_TIMESCALE_ALL_REAL_ROOTS : RBP_TIMESCALE_FIRST_EIGENVALUES);
     if (time_scale != 1) { /* :236-265 */
         for (int qi = 0; qi < N; ++qi) {
             for (int k = 0; k < 3; ++k)
@@ -1348,6 +1589,7 @@ double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan) { /* :209-2
     }
     return time_scale;
 }
+double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan) { return oracle_time_scale_rule(mission, plan, RBP_TIMESCALE_ALL_REAL_ROOTS); }
 
 /* ------------------------------------------------------------------------------------------------
  * solver-independent evaluation of a candidate set of control points
@@ -1480,7 +1722,8 @@ int oracle_planner_update(const rbp_mission* mission, const rbp_param* param_in,
         if (plan->ctrl) memcpy(plan->ctrl, ctrl, sizeof(double) * (size_t)N * 3 * oq);
         plan->total_cost = total_cost;
         plan->time_scale = 1;
-        if (param.time_scale) plan->time_scale = oracle_time_scale(mission, plan); /* :72-77 */
+        plan->time_scale_alt = 1;
+        if (param.time_scale) plan->time_scale = oracle_time_scale_rule(mission, plan, param.timescale_rule); /* :72-77 */
     }
     if (warm != ctrl) free(warm);
     free(ctrl);

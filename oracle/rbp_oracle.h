@@ -76,7 +76,12 @@ int oracle_evaluate_ctrl(const rbp_mission* mission, const rbp_plan* plan, const
 void oracle_ctrl_to_coef(int N, int M, const double* T, const double* ctrl, double* coef);
 
 /* timeScale (rbp_planner.hpp:209-266): returns time_scale and applies it to coef/T/sfc_time/rsfc_time */
-double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan);
+double oracle_time_scale(const rbp_mission* mission, rbp_plan* plan);   /* rule RBP_TIMESCALE_ALL_REAL_ROOTS */
+/* ... under either rule of rbp_param.timescale_rule; plan->time_scale_alt receives the OTHER rule's factor */
+double oracle_time_scale_rule(const rbp_mission* mission, rbp_plan* plan, int rule);
+/* eigenvalues of the companion matrix of c[0] t^deg + ... + c[deg] (deg <= 3, c[0] != 0) in the order of Eigen 3.3's EigenSolver as
+ * restated in oracle/planner.c (roots_derivative, rbp_planner.hpp:737-751); returns deg, 0 = no convergence, -1 = bad argument */
+int oracle_companion_eigenvalues(const double* c, int deg, double* re, double* im);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,10 @@ RBP_ERR_NO_DEVICE = 30
 RBP_ERR_HIP = 31
 RBP_ERR_EXCHANGE = 32
 
-RBP_ABI_VERSION = 5  # include/rbp.h
+RBP_ABI_VERSION = 6  # include/rbp.h
+
+RBP_TIMESCALE_ALL_REAL_ROOTS = 0     # rbp_param.timescale_rule (include/rbp.h)
+RBP_TIMESCALE_FIRST_EIGENVALUES = 1
 
 RBP_STAGE_CORRIDOR = 1
 RBP_STAGE_PLANNER = 2
@@ -52,7 +55,8 @@ class rbp_param(C.Structure):
                 ("ecbs_w", C.c_double), ("grid_xy_res", C.c_double), ("grid_z_res", C.c_double),
                 ("grid_margin", C.c_double),
                 ("n", C.c_int32), ("phi", C.c_int32), ("sequential", C.c_int32), ("batch_size", C.c_int32),
-                ("batch_iter", C.c_int32), ("iteration", C.c_int32), ("time_scale", C.c_int32), ("log", C.c_int32)]
+                ("batch_iter", C.c_int32), ("iteration", C.c_int32), ("time_scale", C.c_int32), ("log", C.c_int32),
+                ("timescale_rule", C.c_int32)]
 
 
 class rbp_plan(C.Structure):
@@ -62,7 +66,7 @@ class rbp_plan(C.Structure):
                 ("coef", c_double_p), ("ctrl", c_double_p),
                 ("time_scale", C.c_double), ("total_cost", C.c_double),
                 ("x_size", C.c_int32), ("eq_size", C.c_int32), ("ineq_size", C.c_int32), ("qp_iterations", C.c_int32),
-                ("qp_solves", C.c_int32), ("qp_unpolished", C.c_int32), ("kkt_max", C.c_double)]
+                ("qp_solves", C.c_int32), ("qp_unpolished", C.c_int32), ("kkt_max", C.c_double), ("time_scale_alt", C.c_double)]
 
 
 class rbp_counters(C.Structure):

@@ -159,6 +159,7 @@ void rbp_param_defaults(rbp_param* p) {  // param.hpp:44-70
     p->time_scale = 1, p->time_step = 1, p->downwash = 2.0;
     p->n = 5, p->phi = 3, p->sequential = 0, p->batch_size = 4, p->batch_iter = 0, p->iteration = 1;
     p->log = 0;
+    p->timescale_rule = RBP_TIMESCALE_ALL_REAL_ROOTS;
 }
 
 void rbp_solver_opts_defaults(rbp_solver_opts* o) {
@@ -213,6 +214,8 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
         M = std::max(M, (int)plans[k].M), MB = std::max(MB, (int)plans[k].max_boxes);
     }
     if (param->n != 5 || param->phi != 3) return fail(RBP_ERR_UNSUPPORTED_DEGREE, "RBPPlanner: n should be 5, phi 3");
+    if (param->timescale_rule != RBP_TIMESCALE_ALL_REAL_ROOTS && param->timescale_rule != RBP_TIMESCALE_FIRST_EIGENVALUES)
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_param.timescale_rule must be RBP_TIMESCALE_ALL_REAL_ROOTS (0) or RBP_TIMESCALE_FIRST_EIGENVALUES (1)");
     // the SFC kernel caches at most SFC_MAXS sample keys per axis (isObstacleInBox walks the box on the box_res lattice,
     // rbp_corridor.hpp:47-63): reject worlds / resolutions that would be truncated instead of growing boxes through obstacles
     if (!(param->box_xy_res > 0) || !(param->box_z_res > 0)) return fail(RBP_ERR_BAD_ARGUMENT, "box/xy_res and box/z_res must be positive");
@@ -318,6 +321,7 @@ static int session_create_impl(rbp_session** out, int device, int K, const rbp_w
     d.p.box_xy_res = param->box_xy_res, d.p.box_z_res = param->box_z_res, d.p.downwash = param->downwash;
     d.p.sequential = param->sequential, d.p.batch_size = param->batch_size, d.p.batch_iter = param->batch_iter;
     d.p.iteration = param->iteration, d.p.time_scale = param->time_scale;
+    d.p.timescale_rule = param->timescale_rule;
     d.p.polish = 1, d.p.far_slack = 0.7;  // (rbp_solver_opts.polish / qp_far_slack of the run)
 
     Arena& A = s->arena;
@@ -539,6 +543,11 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
     if (stages & RBP_STAGE_PLANNER) {
         int rc = ensure_planner_workspace(s, st);
         if (rc) return rc;
+        // refusals of a sharded session BEFORE anything is enqueued or any state of the session changes (joint_wide is known now)
+        if (s->shard.nranks == 2 && !s->joint_wide)
+            return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: this plan does not run on the grid-wide joint solver (rbp_solver_opts.joint_wide_min_agents), there is no factorisation to share");
+        if (s->shard.nranks == 2 && async)
+            return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_run_async: a session sharded over two ranks (rbp_session_shard_joint) calls the exchange hook on the caller's thread: use rbp_session_run");
     }
     s->last_stages = stages;
     s->d.p.polish = o.polish ? 1 : 0;
@@ -547,8 +556,6 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
         int rc = launch_corridor(s->d, st);
         if (rc) return rc;
     }
-    if ((stages & RBP_STAGE_PLANNER) && s->shard.nranks == 2 && !s->joint_wide)
-        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: this plan does not run on the grid-wide joint solver (rbp_solver_opts.joint_wide_min_agents), there is no factorisation to share");
     if ((stages & RBP_STAGE_PLANNER) && s->joint_wide) {
         // grid-wide joint QP: a launch per phase; the host learns once per interior-point iteration whether any mission is still
         // running, so this call SYNCHRONISES the stream (unlike the batch path, which only enqueues)
@@ -556,10 +563,7 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
         int rc = RBP_OK;
         JointOpts jo;
         jo.corrector = o.joint_corrector ? 1 : 0, jo.schedule = o.joint_schedule;
-        if (s->shard.nranks == 2) {
-            if (async) return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_run_async: a session sharded over two ranks (rbp_session_shard_joint) calls the exchange hook on the caller's thread: use rbp_session_run");
-            jo.shard = &s->shard;
-        }
+        if (s->shard.nranks == 2) jo.shard = &s->shard;
         if (async) {
             // rbp_session_run_async: the host loop moves to a thread and a stream of the session's own, ordered after what the caller's
             // stream holds so far (inputs, the CORRIDOR stage, the prologue) by an event
@@ -708,6 +712,7 @@ int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void*
         if (planned && p.coef) DN(p.coef, d.coef + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
         if (planned && p.ctrl) DN(p.ctrl, d.ctrl + (size_t)k * N * 3 * oq, sizeof(double) * (size_t)N * 3 * oqq);
         p.time_scale = ts;
+        p.time_scale_alt = ((s->last_stages & RBP_STAGE_PLANNER) && q[SC_TIME_SCALE_ALT] > 0) ? q[SC_TIME_SCALE_ALT] : 1.0;
         p.total_cost = planned ? q[SC_TOTAL_COST] : 0.0;
         p.qp_iterations = planned ? (int)q[SC_IPM_ITERS] : 0;
         p.qp_solves = planned ? (int)q[SC_QP_SOLVED] : 0;

@@ -2934,14 +2934,259 @@ __device__ int real_roots(const double* cin, int deg, double* out) {
     return n;
 }
 
-// one workgroup per mission: max over (agent, dim, segment) of the per-segment scale, then rescale
+
+// ---- roots_derivative AS WRITTEN (rbp_planner.hpp:727-754): the real ones among the FIRST TWO eigenvalues of the companion matrix --------
+// rbp_param.timescale_rule = RBP_TIMESCALE_FIRST_EIGENVALUES.  Which two of the cubic's three roots the reference's loop `j < i` (:746)
+// sees is decided by the order in which Eigen::EigenSolver deflates them; Eigen is an un-vendored, un-pinned dependency of the reference,
+// so its PUBLISHED algorithm (Eigen 3.3.x RealSchur: scaling by the largest |entry|, Francis double-shift QR with the deflation test
+// |T(k,k-1)| <= eps (|T(k-1,k-1)| + |T(k,k)|), exceptional shifts at local iterations 10 / 30, splitOffTwoRows, eigenvalues read off the
+// quasi-triangular T from the top) is restated here for matrices of order <= 3 -- a documented, deterministic order (include/rbp.h).
+// The Hessenberg reduction is the identity on a companion matrix (its Householder vectors have zero tails) and is left out.
+#pragma clang fp contract(off)  // the order of two nearly symmetric roots can hang on the last bit of a deflation test: same products and sums as oracle/planner.c
+#define ES_EPS 2.220446049250313e-16
+#define ES_MIN 2.2250738585072014e-308
+__device__ inline void es_householder(const double* v, int n, double* ess, double& tau, double& beta) {  // Householder.h makeHouseholder
+    double tail = 0;
+    for (int i = 1; i < n; ++i) tail += v[i] * v[i];
+    const double c0 = v[0];
+    if (tail <= ES_MIN) {
+        tau = 0, beta = c0;
+        for (int i = 1; i < n; ++i) ess[i - 1] = 0;
+    } else {
+        double b = sqrt(c0 * c0 + tail);
+        if (c0 >= 0) b = -b;
+        for (int i = 1; i < n; ++i) ess[i - 1] = v[i] / (c0 - b);
+        tau = (b - c0) / b, beta = b;
+    }
+}
+__device__ inline void es_house_left(double (*T)[3], int r0, int nr, int c0, int c1, const double* ess, double tau) {
+    if (nr == 1) {
+        for (int j = c0; j <= c1; ++j) T[r0][j] *= (1 - tau);
+    } else if (tau != 0) {
+        for (int j = c0; j <= c1; ++j) {
+            double tmp = 0;
+            for (int i = 1; i < nr; ++i) tmp += ess[i - 1] * T[r0 + i][j];
+            tmp += T[r0][j];
+            T[r0][j] -= tau * tmp;
+            for (int i = 1; i < nr; ++i) T[r0 + i][j] -= tau * ess[i - 1] * tmp;
+        }
+    }
+}
+__device__ inline void es_house_right(double (*T)[3], int r0, int r1, int c0, int nc, const double* ess, double tau) {
+    if (nc == 1) {
+        for (int i = r0; i <= r1; ++i) T[i][c0] *= (1 - tau);
+    } else if (tau != 0) {
+        for (int i = r0; i <= r1; ++i) {
+            double tmp = 0;
+            for (int j = 1; j < nc; ++j) tmp += T[i][c0 + j] * ess[j - 1];
+            tmp += T[i][c0];
+            T[i][c0] -= tau * tmp;
+            for (int j = 1; j < nc; ++j) T[i][c0 + j] -= tau * tmp * ess[j - 1];
+        }
+    }
+}
+// eigenvalues of the n x n (n <= 3) upper Hessenberg A in EigenSolver's order; false = the QR iteration did not converge
+__device__ bool es_eigenvalues(const double (*A)[3], int n, double* re, double* im) {
+    double T[3][3], scale = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) scale = fmax(scale, fabs(A[i][j]));
+    if (scale < ES_MIN) {
+        for (int i = 0; i < n; ++i) re[i] = 0, im[i] = 0;
+        return true;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T[i][j] = A[i][j] / scale;
+    double norm = 0;  // computeNormOfT
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < (j + 2 < n ? j + 2 : n); ++i) norm += fabs(T[i][j]);
+    int iu = n - 1, iter = 0, total = 0;
+    double exshift = 0;
+    if (norm != 0)
+        while (iu >= 0) {
+            int il = iu;  // findSmallSubdiagEntry
+            while (il > 0) {
+                const double sd = fabs(T[il - 1][il - 1]) + fabs(T[il][il]);
+                if (fabs(T[il][il - 1]) <= ES_EPS * sd) break;
+                il--;
+            }
+            if (il == iu) {  // one root
+                T[iu][iu] += exshift;
+                if (iu > 0) T[iu][iu - 1] = 0;
+                iu--, iter = 0;
+            } else if (il == iu - 1) {  // splitOffTwoRows
+                const double p = 0.5 * (T[iu - 1][iu - 1] - T[iu][iu]);
+                const double q = p * p + T[iu][iu - 1] * T[iu - 1][iu];
+                T[iu][iu] += exshift, T[iu - 1][iu - 1] += exshift;
+                if (q >= 0) {
+                    const double z = sqrt(fabs(q));
+                    const double gp = (p >= 0) ? p + z : p - z, gq = T[iu][iu - 1];
+                    double c, sn;  // JacobiRotation::makeGivens (real)
+                    if (gq == 0) {
+                        c = gp < 0 ? -1 : 1, sn = 0;
+                    } else if (gp == 0) {
+                        c = 0, sn = gq < 0 ? 1 : -1;
+                    } else if (fabs(gp) > fabs(gq)) {
+                        const double t = gq / gp;
+                        double u = sqrt(1 + t * t);
+                        if (gp < 0) u = -u;
+                        c = 1 / u, sn = -t * c;
+                    } else {
+                        const double t = gp / gq;
+                        double u = sqrt(1 + t * t);
+                        if (gq < 0) u = -u;
+                        sn = -1 / u, c = -t * sn;
+                    }
+                    for (int j = iu - 1; j < n; ++j) {  // rightCols(size - iu + 1).applyOnTheLeft(iu - 1, iu, rot.adjoint())
+                        const double x = T[iu - 1][j], y = T[iu][j];
+                        T[iu - 1][j] = c * x - sn * y, T[iu][j] = sn * x + c * y;
+                    }
+                    for (int i = 0; i <= iu; ++i) {  // topRows(iu + 1).applyOnTheRight(iu - 1, iu, rot)
+                        const double x = T[i][iu - 1], y = T[i][iu];
+                        T[i][iu - 1] = c * x - sn * y, T[i][iu] = sn * x + c * y;
+                    }
+                    T[iu][iu - 1] = 0;
+                }
+                if (iu > 1) T[iu - 1][iu - 2] = 0;
+                iu -= 2, iter = 0;
+            } else {  // il < iu - 1: only n = 3, il = 0, iu = 2
+                double sh0 = T[iu][iu], sh1 = T[iu - 1][iu - 1], sh2 = T[iu][iu - 1] * T[iu - 1][iu];  // computeShift
+                if (iter == 10) {
+                    exshift += sh0;
+                    for (int i = 0; i <= iu; ++i) T[i][i] -= sh0;
+                    const double sd = fabs(T[iu][iu - 1]) + fabs(T[iu - 1][iu - 2]);
+                    sh0 = 0.75 * sd, sh1 = 0.75 * sd, sh2 = -0.4375 * sd * sd;
+                }
+                if (iter == 30) {
+                    double sd = (sh1 - sh0) / 2.0;
+                    sd = sd * sd + sh2;
+                    if (sd > 0) {
+                        sd = sqrt(sd);
+                        if (sh1 < sh0) sd = -sd;
+                        sd = sd + (sh1 - sh0) / 2.0;
+                        sd = sh0 - sh2 / sd;
+                        exshift += sd;
+                        for (int i = 0; i <= iu; ++i) T[i][i] -= sd;
+                        sh0 = sh1 = sh2 = 0.964;
+                    }
+                }
+                iter++, total++;
+                if (total > 40 * n) return false;
+                int imm;  // initFrancisQRStep
+                double v[3] = {0, 0, 0};
+                for (imm = iu - 2; imm >= il; --imm) {
+                    const double Tmm = T[imm][imm], r = sh0 - Tmm, sd = sh1 - Tmm;
+                    v[0] = (r * sd - sh2) / T[imm + 1][imm] + T[imm][imm + 1];
+                    v[1] = T[imm + 1][imm + 1] - Tmm - r - sd;
+                    v[2] = T[imm + 2][imm + 1];
+                    if (imm == il) break;
+                    const double lhs = T[imm][imm - 1] * (fabs(v[1]) + fabs(v[2]));
+                    const double rhs = v[0] * (fabs(T[imm - 1][imm - 1]) + fabs(Tmm) + fabs(T[imm + 1][imm + 1]));
+                    if (fabs(lhs) < ES_EPS * rhs) break;
+                }
+                for (int k = imm; k <= iu - 2; ++k) {  // performFrancisQRStep
+                    const bool first = (k == imm);
+                    double w[3], ess[2], tau, beta;
+                    if (first)
+                        w[0] = v[0], w[1] = v[1], w[2] = v[2];
+                    else
+                        w[0] = T[k][k - 1], w[1] = T[k + 1][k - 1], w[2] = T[k + 2][k - 1];
+                    es_householder(w, 3, ess, tau, beta);
+                    if (beta != 0) {
+                        if (first && k > il)
+                            T[k][k - 1] = -T[k][k - 1];
+                        else if (!first)
+                            T[k][k - 1] = beta;
+                        es_house_left(T, k, 3, k, n - 1, ess, tau);
+                        es_house_right(T, 0, (iu < k + 3 ? iu : k + 3), k, 3, ess, tau);
+                    }
+                }
+                {
+                    double w[2] = {T[iu - 1][iu - 2], T[iu][iu - 2]}, ess[1], tau, beta;
+                    es_householder(w, 2, ess, tau, beta);
+                    if (beta != 0) {
+                        T[iu - 1][iu - 2] = beta;
+                        es_house_left(T, iu - 1, 2, iu - 1, n - 1, ess, tau);
+                        es_house_right(T, 0, iu, iu - 1, 2, ess, tau);
+                    }
+                }
+                for (int i = imm + 2; i <= iu; ++i) {  // clean up pollution due to round-off errors
+                    T[i][i - 2] = 0;
+                    if (i > imm + 2) T[i][i - 3] = 0;
+                }
+            }
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T[i][j] *= scale;
+    for (int i = 0; i < n; ++i) {  // EigenSolver::compute: eigenvalues from the quasi-triangular T, top to bottom
+        if (i == n - 1 || T[i + 1][i] == 0) {
+            re[i] = T[i][i], im[i] = 0;
+        } else {
+            const double p = 0.5 * (T[i][i] - T[i + 1][i + 1]);
+            double t0 = T[i + 1][i], t1 = T[i][i + 1];
+            const double mx = fmax(fabs(p), fmax(fabs(t0), fabs(t1)));
+            t0 /= mx, t1 /= mx;
+            const double p0 = p / mx, z = mx * sqrt(fabs(p0 * p0 + t0 * t1));
+            re[i] = T[i + 1][i + 1] + p, im[i] = z;
+            re[i + 1] = T[i + 1][i + 1] + p, im[i + 1] = -z;
+            ++i;
+        }
+    }
+    return true;
+}
+// roots_derivative(i, coef_der) for the polynomial c[0] t^deg + ... + c[deg]: the real ones among the first `take` eigenvalues (the reference
+// passes the derivative order i = 2 as that bound, :746; with fewer eigenvalues than that it reads past the end -- guarded: j < deg)
+__device__ int first_eigen_roots(const double* cin, int deg, int take, double* out) {
+    const double* c = cin;
+    while (deg > 0 && c[0] == 0) c++, deg--;  // :729-733
+    if (deg == 0) return 0;
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, re[3], im[3];
+    for (int j = 0; j < deg; ++j) {  // :737-744
+        if (j < deg - 1) A[j + 1][j] = 1;
+        A[0][j] = -c[j + 1] / c[0];
+    }
+    if (!es_eigenvalues(A, deg, re, im)) return 0;
+    int n = 0;
+    for (int j = 0; j < take && j < deg; ++j)
+        if (im[j] == 0) out[n++] = re[j];
+    return n;
+}
+#pragma clang fp contract(fast)
+
+// scale_to_max_vel :756-794 with the candidate roots of one rule
+__device__ double vel_scale(const double (*cd)[6], const double* roots, int nroots, double dt, double lim) {
+    const int n = 5;
+    double tsx[8];
+    int nt = 0;
+    for (int a = 0; a < nroots; ++a) tsx[nt++] = roots[a];
+    tsx[nt++] = 0, tsx[nt++] = dt;
+    double vel_max = 0, t_max = 0;
+    for (int a = 0; a < nt; ++a) {
+        const double t = tsx[a];
+        if (t < 0 || t > dt) continue;
+        double vel = 0;
+        for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(t, n - 1 - i);
+        vel = fabs(vel);
+        if (vel_max < vel) vel_max = vel, t_max = t;
+    }
+    double sc = 1;
+    while (vel_max > lim && sc < 1e6) {
+        sc *= 1.1;
+        double vel = 0;
+        for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(1 / sc, n - i) * pow(t_max, n - 1 - i);
+        vel_max = fabs(vel);
+    }
+    return sc;
+}
+
+// one workgroup per mission: max over (agent, dim, segment) of the per-segment scale under BOTH rules of rbp_param.timescale_rule, then
+// rescale by the selected one
 __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
     const int mission = blockIdx.x, tid = threadIdx.x, M = s.Mk[mission], MS = s.M, N = s.N, oq = 6 * M, n = 5;
     if (s.status[mission] != 0) return;
     __shared__ double red[8];
     const double* T = s.T + (size_t)mission * (MS + 1);
     double* coef = s.coef + (size_t)mission * N * 3 * 6 * MS;
-    double ts = 1;
+    double ts = 1, ts1 = 1;  // all real roots / the first two eigenvalues
     if (s.p.time_scale) {
         for (int it = tid; it < N * 3 * M; it += blockDim.x) {
             const int qi = it / (3 * M), k = (it / M) % 3, m = it % M;
@@ -2950,28 +3195,16 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 6; ++j) cd[i][n - j] = (i <= j) ? coef_derivative(i, j) * cf[n - j] : 0.0;
             const double dt = T[m + 1] - T[m];
-            {  // scale_to_max_vel :756-794
-                double tsx[8];
-                int nt = real_roots(cd[2], 3, tsx);
-                tsx[nt++] = 0, tsx[nt++] = dt;
-                double vel_max = 0, t_max = 0;
-                for (int a = 0; a < nt; ++a) {
-                    const double t = tsx[a];
-                    if (t < 0 || t > dt) continue;
-                    double vel = 0;
-                    for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(t, n - 1 - i);
-                    vel = fabs(vel);
-                    if (vel_max < vel) vel_max = vel, t_max = t;
-                }
-                double sc = 1;
+            {  // scale_to_max_vel :756-794, under both root rules
+                double r0[3], r1[3];
+                const int n0 = real_roots(cd[2], 3, r0), n1 = first_eigen_roots(cd[2], 3, 2, r1);  // roots_derivative(2, coef_der) :761
                 const double lim = s.max_vel[((size_t)mission * N + qi) * 3 + k];
-                while (vel_max > lim && sc < 1e6) {
-                    sc *= 1.1;
-                    double vel = 0;
-                    for (int i = 0; i <= n - 1; ++i) vel += cd[1][i] * pow(1 / sc, n - i) * pow(t_max, n - 1 - i);
-                    vel_max = fabs(vel);
-                }
-                if (ts < sc) ts = sc;
+                const double sc0 = vel_scale(cd, r0, n0, dt, lim);
+                bool same = n0 == n1;
+                for (int a = 0; same && a < n0; ++a) same = r0[a] == r1[a];
+                const double sc1 = same ? sc0 : vel_scale(cd, r1, n1, dt, lim);
+                if (ts < sc0) ts = sc0;
+                if (ts1 < sc1) ts1 = sc1;
             }
             {  // scale_to_max_acc :797-847
                 const double a = cd[3][0], b = cd[3][1], cc = cd[3][2], D = b * b - 4 * a * cc;
@@ -3000,17 +3233,22 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
                     acc_max = fabs(acc);
                 }
                 if (ts < sc) ts = sc;
+                if (ts1 < sc) ts1 = sc;
             }
         }
         // block max
-        for (int o = 32; o > 0; o >>= 1) ts = fmax(ts, __shfl_xor(ts, o));
-        if ((tid & 63) == 0) red[tid >> 6] = ts;
+        for (int o = 32; o > 0; o >>= 1) ts = fmax(ts, __shfl_xor(ts, o)), ts1 = fmax(ts1, __shfl_xor(ts1, o));
+        if ((tid & 63) == 0) red[tid >> 6] = ts, red[4 + (tid >> 6)] = ts1;
         __syncthreads();
-        ts = red[0];
-        for (int i = 1; i < (int)blockDim.x / 64; ++i) ts = fmax(ts, red[i]);
+        ts = red[0], ts1 = red[4];
+        for (int i = 1; i < (int)blockDim.x / 64; ++i) ts = fmax(ts, red[i]), ts1 = fmax(ts1, red[4 + i]);
         __syncthreads();
+        if (s.p.timescale_rule == RBP_TIMESCALE_FIRST_EIGENVALUES) {
+            const double t = ts;
+            ts = ts1, ts1 = t;
+        }
     }
-    if (tid == 0) s.scalars[(size_t)mission * SC_N + SC_TIME_SCALE] = ts;
+    if (tid == 0) s.scalars[(size_t)mission * SC_N + SC_TIME_SCALE] = ts, s.scalars[(size_t)mission * SC_N + SC_TIME_SCALE_ALT] = ts1;
     // :236-265.  Only the coefficients are rescaled on the device: T, the SFC end times and the RSFC times stay as uploaded /
     // as the corridor stage wrote them (so a session can be re-run without restoring anything) and rbp_session_download
     // multiplies its host copies by time_scale -- the same IEEE product the reference computes in place (:250-264).

@@ -37,6 +37,7 @@ struct DevParam {
     double world_min[3], world_max[3];
     double box_xy_res, box_z_res, downwash;
     int sequential, batch_size, batch_iter, iteration, time_scale;
+    int timescale_rule;  // rbp_param.timescale_rule (RBP_TIMESCALE_*)
     int polish;  // 1: active-set polish after the interior-point solve (default)
     double far_slack;  // rbp_solver_opts.qp_far_slack (kernels/qp.hip QP_FAR_SLACK); <= 0: every row near
 };
@@ -81,7 +82,8 @@ enum { SC_TIME_SCALE = 0, SC_TOTAL_COST = 1, SC_IPM_ITERS = 2, SC_QP_SOLVED = 3,
        SC_PROF0 = 8,      // SC_PROF0..SC_PROF0+15: per-phase cycle counters (QP_PROFILE builds); slot 8 otherwise: which batch was not polished
        SC_ROW_BYTES = 24, // algorithmic HBM bytes of the QP kernel (row state, row constants, knot blocks)
        SC_SWEEP_BYTES = 28, // ... the part of SC_ROW_BYTES the three row sweeps of an interior-point iteration stream (bench.py: sweep_phase_gbs)
-       SC_N = 32 };
+       SC_TIME_SCALE_ALT = 32, // the factor the other rule of rbp_param.timescale_rule gives (rbp_plan::time_scale_alt)
+       SC_N = 36 };
 enum { CT_SFC_SAMPLES = 0, CT_N = 4 };
 
 int rbp_set_error(int code, const char* msg);  // abi/session.hip: records the message rbp_last_error() returns, returns code

@@ -281,6 +281,7 @@ class Session:
             raise RuntimeError(f"rbp_session_set_solver_opts rc={rc}: {last_error()}")
 
     def run(self, stages=A.RBP_STAGE_ALL, stream=None):
+        self._xchg_error = None   # (an exchange hook's exception belongs to the run it happened in)
         rc = lib().rbp_session_run(self._h, stages, C.c_void_p(stream or 0))
         if rc:
             cause = getattr(self, "_xchg_error", None)
@@ -307,6 +308,7 @@ class Session:
         if dist is None:
             rc = lib().rbp_session_shard_joint(self._h, 0, 1, EXCHANGE_FN(), None)
             self._xchg = None
+            self._xchg_error = None
             if rc:
                 raise RuntimeError(f"rbp_session_shard_joint rc={rc}: {last_error()}")
             return

@@ -73,6 +73,7 @@ class Param:
     batch_size: int = 4
     batch_iter: int = 0
     iteration: int = 1
+    timescale_rule: int = 0   # NOT a key of the reference: include/rbp.h RBP_TIMESCALE_* (0 = every real root, 1 = roots_derivative's first two eigenvalues)
 
     @classmethod
     def random_forest(cls, **kw):
@@ -99,6 +100,7 @@ class Param:
         p.n, p.phi = self.n, self.phi
         p.sequential, p.batch_size, p.batch_iter, p.iteration = int(self.sequential), self.batch_size, self.batch_iter, self.iteration
         p.time_scale, p.log = int(self.time_scale), int(self.log)
+        p.timescale_rule = int(self.timescale_rule)
         return p
 
 
@@ -148,6 +150,7 @@ class PlanResult:
         self.coef = np.zeros((N, 3, 6 * M), np.float64)
         self.ctrl = np.zeros((N, 3, 6 * M), np.float64)
         self.time_scale = 1.0
+        self.time_scale_alt = 1.0   # the other rule's factor (rbp_param.timescale_rule)
         self.total_cost = 0.0
         self.x_size = self.eq_size = self.ineq_size = 0
         self.qp_iterations = 0
@@ -179,6 +182,7 @@ class PlanResult:
         self.x_size, self.eq_size, self.ineq_size = p.x_size, p.eq_size, p.ineq_size
         self.qp_iterations = p.qp_iterations
         self.qp_solves, self.qp_unpolished, self.kkt_max = p.qp_solves, p.qp_unpolished, p.kkt_max
+        self.time_scale_alt = p.time_scale_alt
 
     def clone_inputs(self):
         return PlanResult(self.init_traj.copy(), self.T.copy(), self.max_boxes)

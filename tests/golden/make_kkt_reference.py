@@ -384,6 +384,171 @@ def _roots_reference_rule(cd, i):
     return [float(np.real(ev[j])) for j in range(min(i, len(ev))) if np.imag(ev[j]) == 0]
 
 
+
+def eigen33_eigenvalues(A):
+    """Eigenvalues of a small real upper-Hessenberg matrix in the order Eigen 3.3.x's EigenSolver returns them, restated with whole-matrix
+    reflections from the published algorithm (RealSchur.h: scale by max|a_ij|, Francis double-shift QR, deflation test
+    |t(k,k-1)| <= eps (|t(k-1,k-1)| + |t(k,k)|), exceptional shifts at local iterations 10 and 30, a trailing 2 x 2 block with real
+    eigenvalues is rotated to triangular form; EigenSolver.h: read T from the top).  Independent of oracle/planner.c's element-wise
+    restatement of the same algorithm -- the two are compared in tests/test_timescale_rule.py."""
+    A = np.array(A, dtype=np.float64)
+    n = A.shape[0]
+    scale = np.abs(A).max()
+    if scale < np.finfo(float).tiny:
+        return [complex(0.0)] * n
+    T = A / scale
+    eps = np.finfo(float).eps
+
+    def reflector(v):
+        """(essential part, tau, beta) of the Householder reflection H = I - tau [1; ess][1; ess]' with H v = beta e1 (Householder.h)"""
+        tail = float(np.dot(v[1:], v[1:]))
+        if tail <= np.finfo(float).tiny:
+            return np.zeros(len(v) - 1), 0.0, float(v[0])
+        beta = np.sqrt(v[0] * v[0] + tail)
+        if v[0] >= 0:
+            beta = -beta
+        return v[1:] / (v[0] - beta), (beta - v[0]) / beta, beta
+
+    def H_of(ess, tau, k):
+        u = np.zeros(n)
+        u[k] = 1.0
+        u[k + 1:k + 1 + len(ess)] = ess
+        return np.eye(n) - tau * np.outer(u, u)
+
+    iu, it, total, exshift = n - 1, 0, 0, 0.0
+    while iu >= 0:
+        il = iu
+        while il > 0 and not (abs(T[il, il - 1]) <= eps * (abs(T[il - 1, il - 1]) + abs(T[il, il]))):
+            il -= 1
+        if il == iu:
+            T[iu, iu] += exshift
+            if iu > 0:
+                T[iu, iu - 1] = 0.0
+            iu, it = iu - 1, 0
+        elif il == iu - 1:
+            p = 0.5 * (T[iu - 1, iu - 1] - T[iu, iu])
+            q = p * p + T[iu, iu - 1] * T[iu - 1, iu]
+            T[iu, iu] += exshift
+            T[iu - 1, iu - 1] += exshift
+            if q >= 0:
+                z = np.sqrt(abs(q))
+                gp, gq = (p + z if p >= 0 else p - z), T[iu, iu - 1]
+                if gq == 0:
+                    c, sn = (-1.0 if gp < 0 else 1.0), 0.0
+                elif gp == 0:
+                    c, sn = 0.0, (1.0 if gq < 0 else -1.0)
+                elif abs(gp) > abs(gq):
+                    t = gq / gp
+                    u = np.sqrt(1 + t * t) * (-1.0 if gp < 0 else 1.0)
+                    c = 1 / u
+                    sn = -t * c
+                else:
+                    t = gp / gq
+                    u = np.sqrt(1 + t * t) * (-1.0 if gq < 0 else 1.0)
+                    sn = -1 / u
+                    c = -t * sn
+                G = np.eye(n)
+                G[iu - 1, iu - 1], G[iu - 1, iu], G[iu, iu - 1], G[iu, iu] = c, -sn, sn, c   # rows: x' = c x - s y, y' = s x + c y
+                T[:, iu - 1:] = (G @ T)[:, iu - 1:]
+                T[:iu + 1, :] = (T @ G.T)[:iu + 1, :]
+                T[iu, iu - 1] = 0.0
+            if iu > 1:
+                T[iu - 1, iu - 2] = 0.0
+            iu, it = iu - 2, 0
+        else:
+            sh = [T[iu, iu], T[iu - 1, iu - 1], T[iu, iu - 1] * T[iu - 1, iu]]
+            if it == 10:
+                exshift += sh[0]
+                T[np.arange(iu + 1), np.arange(iu + 1)] -= sh[0]
+                sd = abs(T[iu, iu - 1]) + abs(T[iu - 1, iu - 2])
+                sh = [0.75 * sd, 0.75 * sd, -0.4375 * sd * sd]
+            if it == 30:
+                sd = (sh[1] - sh[0]) / 2.0
+                sd = sd * sd + sh[2]
+                if sd > 0:
+                    sd = np.sqrt(sd)
+                    if sh[1] < sh[0]:
+                        sd = -sd
+                    sd = sd + (sh[1] - sh[0]) / 2.0
+                    sd = sh[0] - sh[2] / sd
+                    exshift += sd
+                    T[np.arange(iu + 1), np.arange(iu + 1)] -= sd
+                    sh = [0.964, 0.964, 0.964]
+            it, total = it + 1, total + 1
+            if total > 40 * n:
+                raise RuntimeError("no convergence")
+            im = iu - 2
+            while True:
+                Tmm = T[im, im]
+                r, sd = sh[0] - Tmm, sh[1] - Tmm
+                v = np.array([(r * sd - sh[2]) / T[im + 1, im] + T[im, im + 1], T[im + 1, im + 1] - Tmm - r - sd, T[im + 2, im + 1]])
+                if im == il:
+                    break
+                lhs = T[im, im - 1] * (abs(v[1]) + abs(v[2]))
+                rhs = v[0] * (abs(T[im - 1, im - 1]) + abs(Tmm) + abs(T[im + 1, im + 1]))
+                if abs(lhs) < eps * rhs:
+                    break
+                im -= 1
+            for k in range(im, iu - 1):
+                first = k == im
+                w = v if first else T[k:k + 3, k - 1].copy()
+                ess, tau, beta = reflector(w)
+                if beta != 0:
+                    if first and k > il:
+                        T[k, k - 1] = -T[k, k - 1]
+                    elif not first:
+                        T[k, k - 1] = beta
+                    H = H_of(ess, tau, k)
+                    T[k:k + 3, k:] = (H @ T)[k:k + 3, k:]
+                    rows = min(iu, k + 3) + 1
+                    T[:rows, k:k + 3] = (T @ H)[:rows, k:k + 3]
+            ess, tau, beta = reflector(T[iu - 1:iu + 1, iu - 2].copy())
+            if beta != 0:
+                T[iu - 1, iu - 2] = beta
+                H = H_of(ess, tau, iu - 1)
+                T[iu - 1:iu + 1, iu - 1:] = (H @ T)[iu - 1:iu + 1, iu - 1:]
+                T[:iu + 1, iu - 1:iu + 1] = (T @ H)[:iu + 1, iu - 1:iu + 1]
+            for i in range(im + 2, iu + 1):
+                T[i, i - 2] = 0.0
+                if i > im + 2:
+                    T[i, i - 3] = 0.0
+    T = T * scale
+    ev, i = [], 0
+    while i < n:
+        if i == n - 1 or T[i + 1, i] == 0:
+            ev.append(complex(T[i, i], 0.0))
+            i += 1
+        else:
+            p = 0.5 * (T[i, i] - T[i + 1, i + 1])
+            t0, t1 = T[i + 1, i], T[i, i + 1]
+            mx = max(abs(p), abs(t0), abs(t1))
+            z = mx * np.sqrt(abs((p / mx) * (p / mx) + (t0 / mx) * (t1 / mx)))
+            ev += [complex(T[i + 1, i + 1] + p, z), complex(T[i + 1, i + 1] + p, -z)]
+            i += 2
+    return ev
+
+
+def companion(c):
+    """the reference's companion matrix of c[0] t^d + ... + c[d] (:737-744)"""
+    d = len(c) - 1
+    A = np.zeros((d, d))
+    for j in range(d):
+        if j < d - 1:
+            A[j + 1, j] = 1
+        A[0, j] = -c[j + 1] / c[0]
+    return A
+
+
+def _roots_eigen33_rule(cd, i):
+    """roots_derivative(i, coef_der) as written (:727-754) with Eigen 3.3's eigenvalue order (eigen33_eigenvalues)"""
+    n = 5
+    p = np.trim_zeros(cd[i, :n - i + 1], "f")
+    if len(p) <= 1:
+        return []
+    ev = eigen33_eigenvalues(companion(p))
+    return [ev[j].real for j in range(min(i, len(ev))) if ev[j].imag == 0]
+
+
 def _roots_all_real(cd, i):
     n = 5
     p = cd[i, :n - i + 1]
@@ -394,10 +559,11 @@ def _roots_all_real(cd, i):
 
 
 def time_scale_of(coef, T, max_vel, max_acc, rule):
-    """timeScale's factor (:209-233) for coef [N][3][6M] (descending powers per segment); rule: 'reference' | 'all_real'"""
+    """timeScale's factor (:209-233) for coef [N][3][6M] (descending powers per segment); rule: 'reference' (first two eigenvalues,
+    LAPACK's order) | 'eigen33' (first two eigenvalues, Eigen 3.3's order: rbp_param.timescale_rule = 1) | 'all_real' (= 0)"""
     N, _, oq = coef.shape
     M = oq // 6
-    roots = _roots_reference_rule if rule == "reference" else _roots_all_real
+    roots = {"reference": _roots_reference_rule, "eigen33": _roots_eigen33_rule, "all_real": _roots_all_real}[rule]
     ts_all = 1.0
     for qi in range(N):
         for k in range(3):

@@ -63,6 +63,10 @@ def lib():
         L.oracle_ctrl_to_coef.restype = None
         L.oracle_time_scale.argtypes = [P(A.rbp_mission), P(A.rbp_plan)]
         L.oracle_time_scale.restype = C.c_double
+        L.oracle_time_scale_rule.argtypes = [P(A.rbp_mission), P(A.rbp_plan), C.c_int]
+        L.oracle_time_scale_rule.restype = C.c_double
+        L.oracle_companion_eigenvalues.argtypes = [A.c_double_p, C.c_int, A.c_double_p, A.c_double_p]
+        L.oracle_companion_eigenvalues.restype = C.c_int
         _lib = L
     return _lib
 
@@ -143,9 +147,21 @@ def ctrl_to_coef(T, ctrl):
     return coef
 
 
-def time_scale(mission: Mission, plan: PlanResult):
-    """oracle_time_scale (rbp_planner.hpp:209-266): returns the factor and rescales plan.coef / T / corridor times in place."""
+def time_scale(mission: Mission, plan: PlanResult, rule=0):
+    """oracle_time_scale_rule (rbp_planner.hpp:209-266): returns the factor under rbp_param.timescale_rule = rule and rescales plan.coef / T /
+    corridor times in place; plan.time_scale_alt receives the other rule's factor."""
     m, pl = mission.c_struct(), plan.c_struct()
-    ts = lib().oracle_time_scale(C.byref(m), C.byref(pl))
+    ts = lib().oracle_time_scale_rule(C.byref(m), C.byref(pl), int(rule))
     plan.sync_from(pl)
+    plan.time_scale = ts
     return ts
+
+
+def companion_eigenvalues(c):
+    """eigenvalues of the companion matrix of c[0] t^d + ... + c[d] in the order of Eigen 3.3's EigenSolver (oracle/planner.c es_eigenvalues)"""
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    d = len(c) - 1
+    re, im = np.zeros(3), np.zeros(3)
+    n = lib().oracle_companion_eigenvalues(A.ptr(c, A.c_double_p), d, A.ptr(re, A.c_double_p), A.ptr(im, A.c_double_p))
+    assert n == d, n
+    return re[:d] + 1j * im[:d]
