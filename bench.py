@@ -394,9 +394,12 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but {n_ranks} rank(s) were launched; reporting n_gpus={n_ranks}", file=sys.stderr)
     if args.dry_run:
         n_total, secs = aggregate(args.missions_per_gpu * args.agents, 1.0, dist)
+        extra = {}
+        if args.config == "c4":
+            extra = dry_run_c4(args, rank, n_ranks, dist)
         if rank == 0:
             print(json.dumps({"metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": None, "n_gpus": n_ranks, "dry_run": True,
-                              "agents_all_ranks": n_total, "maps_rank0": shard_missions(min(args.missions_per_gpu, 4), rank, n_ranks)}))
+                              "agents_all_ranks": n_total, "maps_rank0": shard_missions(min(args.missions_per_gpu, 4), rank, n_ranks), **extra}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -600,6 +603,42 @@ def main():
     sess.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dry_run_c4(args, rank, n_ranks, dist):
+    """--config c4 --dry-run (no GPU): the exchange of the agent-sharded corridor with the real partition and the real fused all-gather
+    (swarm_simulator_amd/sharded.py) on a synthetic 256-agent plan -- every rank fills ONLY its shard with values that name their agent /
+    pair row, the rest is poison; after the gather every rank must hold every agent's values.  Returns what rank 0 prints."""
+    import numpy as np
+    from swarm_simulator_amd import sharded
+    from swarm_simulator_amd.types import PlanResult
+    N, M = args.agents, 5
+    slices = sharded.agent_slices(N, n_ranks)
+    plan = PlanResult(np.zeros((N, M + 1, 3), np.float32), np.arange(M + 1, dtype=np.float64))
+    plan.sfc_count[:] = -7
+    plan.sfc_box[:] = np.nan
+    plan.sfc_time[:] = np.nan
+    plan.rsfc_normal[:] = np.nan
+    b, e = slices[rank]
+    o0, o1 = sharded.pair_offset(N, b), sharded.pair_offset(N, e)
+    plan.sfc_count[b:e] = 1 + np.arange(b, e) % M
+    plan.sfc_box[b:e] = np.arange(b, e, dtype=np.float64)[:, None, None] + 0.25
+    plan.sfc_time[b:e] = np.arange(b, e, dtype=np.float64)[:, None] + 0.5
+    plan.rsfc_normal[o0:o1] = -np.arange(o0, o1, dtype=np.float32)[:, None, None]   # (row 0 is -0.0: the sign must survive)
+    if dist is not None:
+        sharded.gather_corridor(dist, plan, N, slices)
+    npair = N * (N - 1) // 2
+    ok = bool(np.array_equal(plan.sfc_count, 1 + np.arange(N) % M) and np.array_equal(plan.sfc_box[:, 0, 0], np.arange(N) + 0.25)
+              and np.array_equal(plan.sfc_time[:, -1], np.arange(N) + 0.5) and np.array_equal(plan.rsfc_normal[:, 0, 0], -np.arange(npair, dtype=np.float32))
+              and np.signbit(plan.rsfc_normal[0, 0, 0]))
+    oks = [ok]
+    if dist is not None:
+        import torch
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        oks = [bool(t.item())]
+    pairs = sharded.pair_group(dist) is not None if (dist is not None and args.joint) else False
+    return {"c4_agent_slices": slices, "c4_gather_ok_on_every_rank": oks[0], "c4_joint_rank_pairs": pairs}
 
 
 def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):

@@ -227,7 +227,14 @@ int rbp_session_wait(rbp_session* s);
  * (the library owns send_dev / recv_dev, in HBM; the session's stream is synchronised before the hook is called; the hook returns 0 once the
  * peer's `bytes` are in recv_dev, e.g. an all-gather over RCCL / xGMI -- swarm_simulator_amd/sharded.py): the explicit inverse of each
  * chain's last knot (81 N^2 doubles rounded up to 64-wide tiles: 42 MB at 256 agents), and two vectors per Newton solve.  The hook is
- * called on the thread that calls rbp_session_run; rbp_session_run_async is refused for a sharded session.  nranks must be 2 (1 = undo). */
+ * called on the thread that calls rbp_session_run; rbp_session_run_async is refused for a sharded session.  nranks must be 2 (1 = undo).
+ * KEEPING THE RANKS MATCHED.  Only the replicated state keeps the two ranks' exchanges paired, so every exchange begins with a 64-byte
+ * header (sequence number, kind, byte count, a hash of the state words the rank polled last, a poison word) that each rank compares with
+ * its own after the hook has returned: ranks that have diverged -- or a peer that failed on its side and sent the poison word in place of
+ * its next exchange -- end the run with RBP_ERR_EXCHANGE and a message naming the word, instead of a hang or a payload unpacked into the
+ * wrong slot.  A hook that fails (non-zero return) ends the run with RBP_ERR_EXCHANGE on that rank; the peer is then blocked in ITS hook, so
+ * a hook must not wait for ever: rbp_rccl_exchange (include/rbp_rccl.h) polls with a timeout and aborts its communicator, which releases the
+ * peer.  After RBP_ERR_EXCHANGE on either rank BOTH ranks must give the solve up (undo the sharding, make a new pair). */
 typedef int (*rbp_exchange_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes);
 int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user);
 /* solver options of this session (default: the context's, else rbp_solver_opts_defaults).  The QP workspace is reserved by the first

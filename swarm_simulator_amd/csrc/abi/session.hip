@@ -588,7 +588,8 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
             return RBP_OK;
         }
         if (s->d.p.iteration > 0) rc = launch_planner_joint(s->d, s->qp_ws, st, &s->joint_stats, jo);
-        if (rc) return fail(rc, rc == RBP_ERR_EXCHANGE ? "joint QP: the exchange hook of rbp_session_shard_joint reported a failure" : "joint QP: HIP error");
+        if (rc == RBP_ERR_EXCHANGE) return rc;  // (kernels/jqp.hip has recorded which exchange failed and why)
+        if (rc) return fail(rc, "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
     } else if ((stages & RBP_STAGE_PLANNER) && o.qp_schedule == 2) {
         // phase split (kernels/qp_phase.inc): chip-wide row sweeps, one workgroup per mission for the chains; the missions are spread over a

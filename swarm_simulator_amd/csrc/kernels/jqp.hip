@@ -1776,6 +1776,13 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
 // the middle solve, jq_mv mode 1, reads both); 2: the chain's rows of the solution in rhs (slot = (njS / 2) nkp).  Bytes only --
 // nothing is added, so both ranks hold bit-identical vectors afterwards.  The gates are those of the kernels that produced the data.
 // ------------------------------------------------------------------------------------------------------------------------
+// Every exchange starts with a header of JQ_XHDR doubles written by the host (launch_planner_joint): the two ranks run the same host
+// loop on replicated state, and nothing else keeps their send / recv pairs matched -- so each exchange carries its sequence number, its
+// kind, its payload size and a hash of the state words the rank polled last, all compared with the rank's own after the hook returns;
+// a mismatch (the ranks have diverged: the payload would be unpacked into the wrong slot) ends the run with RBP_ERR_EXCHANGE instead of
+// a hang or silently wrong data.  Slot 5 is the poison word: a rank that fails locally sends it so that its peer stops too.
+#define JQ_XHDR 8
+#define JQ_XMAGIC 1380077656.0 /* "RBPX" */
 __global__ __launch_bounds__(256) void jq_xfer(JArgs A, int what, int dir, int chain, double* buf) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
@@ -1793,12 +1800,20 @@ __global__ __launch_bounds__(256) void jq_xfer(JArgs A, int what, int dir, int c
     double* dev;
     size_t n, slot;
     if (what == 0)
-        dev = w.inv + (size_t)last * A.L.nkpS * A.L.nkpS, n = nkp2, slot = (size_t)A.L.nkpS * A.L.nkpS;
+        dev = w.inv + (size_t)last * A.L.nkpS * A.L.nkpS, n = nkp2, slot = (size_t)A.L.nkpS * A.L.nkpS + 1;  // (+ 1: the chain's bad-pivot flag)
     else if (what == 1)
         dev = w.wv + (size_t)last * nkp, n = nkp, slot = A.L.nkpS;
     else
         dev = w.rhs + (size_t)first * nkp, n = (size_t)nsteps * nkp, slot = (size_t)(A.L.njS / 2) * A.L.nkpS;
     double* b = buf + (size_t)mission * slot;
+    if (what == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        // a non-positive pivot seen by ONE chain's rank must reach the other: ST_BADPIV feeds ST_REASON, which is replicated state
+        // (both ranks report the same failure reason).  Set-only on the receiving side, like the sweeps' own plain stores.
+        if (dir == 0)
+            b[slot - 1] = w.st[ST_BADPIV];
+        else if (b[slot - 1] != 0.0)
+            w.st[ST_BADPIV] = 1.0;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         if (dir == 0)
             b[i] = dev[i];
@@ -1935,9 +1950,9 @@ JLayout jq_layout(int N, int MS) {
 }
 
 size_t joint_workspace_bytes(int N, int MS) { return jq_layout(N, MS).stride * sizeof(double); }
-size_t joint_exchange_bytes(int N, int MS, int K) {  // the largest of jq_xfer's three slots is the inverse
+size_t joint_exchange_bytes(int N, int MS, int K) {  // header + the largest of jq_xfer's three slots (the inverse and its flag)
     const JDims d = jdims(N, MS);
-    return (size_t)K * std::max((size_t)d.nkp * d.nkp, (size_t)(d.nj / 2 + 1) * d.nkp) * sizeof(double);
+    return (JQ_XHDR + (size_t)K * std::max((size_t)d.nkp * d.nkp + 1, (size_t)(d.nj / 2 + 1) * d.nkp)) * sizeof(double);
 }
 
 #define JQ_LAUNCH(kern, grid, lds, ...) hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, __VA_ARGS__)
@@ -2010,21 +2025,64 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     const int ychains = sh ? 1 : 2, my_chain = sh ? sh->rank : 0;
     int xrc = RBP_OK;
     if (sh && (!sh->exchange || !sh->send || !sh->recv || sh->cap < joint_exchange_bytes(N, s.M, K) || sh->rank < 0 || sh->rank > 1)) return RBP_ERR_BAD_ARGUMENT;
+    double xseq = 0;
+    auto state_hash = [&]() {  // FNV-1a over the state words polled last and the host variables the launch pattern depends on
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) {
+            const unsigned char* c = (const unsigned char*)p;
+            for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+        };
+        mix(state_h, sizeof(double) * (size_t)K * ST_N);
+        mix(&nref_round, sizeof(nref_round));
+        mix(&A.ref_gate, sizeof(A.ref_gate)), mix(&A.gond_only, sizeof(A.gond_only));
+        return (double)(h >> 11);  // (53 bits: exact in a double)
+    };
+    // a rank that cannot go on (HIP error on its side) tells its peer before it returns: one header-only exchange with the poison word
+    // set.  If the hook itself is what failed there is nobody to tell through it: the hook's owner must bring the peer down
+    // (rbp_rccl_exchange aborts its communicator), both ranks must abort together (include/rbp.h).
+    auto xslot = [&](int what) { return what == 0 ? (size_t)dm.nkp * dm.nkp + 1 : what == 1 ? (size_t)dm.nkp : (size_t)(dm.nj / 2) * dm.nkp; };
+    // (send / recv pairs must match in size: the poisoned message has the size of the exchange the peer is about to make, `what`)
+    auto poison_peer = [&](int what) {
+        const size_t bytes = (JQ_XHDR + (size_t)K * xslot(what)) * sizeof(double);
+        double h[JQ_XHDR] = {JQ_XMAGIC, xseq, (double)what, (double)bytes, 0.0, 1.0, 0.0, 0.0};
+        if (hipMemcpy(sh->send, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess) (void)sh->exchange(sh->user, sh->send, sh->recv, bytes);
+    };
     auto exchange = [&](int what) {
         if (xrc != RBP_OK) return;
-        const size_t slot = what == 0 ? (size_t)dm.nkp * dm.nkp : what == 1 ? (size_t)dm.nkp : (size_t)(dm.nj / 2) * dm.nkp;
+        const size_t slot = xslot(what);
         if (slot == 0) return;
+        const size_t bytes = (JQ_XHDR + (size_t)K * slot) * sizeof(double);
         const dim3 grid((unsigned)std::min<size_t>((slot + 255) / 256, 2048), K);
-        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send);
-        if (hipStreamSynchronize(st) != hipSuccess) {
+        const double mine[JQ_XHDR] = {JQ_XMAGIC, xseq, (double)what, (double)bytes, state_hash(), 0.0, 0.0, 0.0};
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send + JQ_XHDR);
+        if (hipMemcpyAsync(sh->send, mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            xrc = RBP_ERR_HIP;
+            poison_peer(what);
+            return;
+        }
+        if (sh->exchange(sh->user, sh->send, sh->recv, bytes) != 0) {
+            xrc = RBP_ERR_EXCHANGE;
+            (void)rbp_set_error(RBP_ERR_EXCHANGE, "joint QP: the exchange hook of rbp_session_shard_joint reported a failure");
+            return;
+        }
+        double peer[JQ_XHDR];
+        if (hipMemcpy(peer, sh->recv, sizeof(peer), hipMemcpyDeviceToHost) != hipSuccess) {
             xrc = RBP_ERR_HIP;
             return;
         }
-        if (sh->exchange(sh->user, sh->send, sh->recv, (size_t)K * slot * sizeof(double)) != 0) {
-            xrc = RBP_ERR_EXCHANGE;
+        static const char* const names[6] = {"magic", "sequence number", "kind", "byte count", "state hash", "poison word (the peer rank failed)"};
+        const int order[6] = {0, 5, 1, 2, 3, 4};  // (a poisoned header is reported as such, whatever else it carries)
+        for (int oi = 0; oi < 6; ++oi) {
+            const int f = order[oi];
+            if (peer[f] == mine[f]) continue;
+            char msg[320];
+            snprintf(msg, sizeof(msg), "joint QP: exchange %.0f (kind %d) does not match the peer rank's: %s differs (mine %.17g, the peer's %.17g) -- the two ranks of "
+                     "the pair have diverged or one has failed; both must abort", xseq, what, names[f], mine[f], peer[f]);
+            xrc = rbp_set_error(RBP_ERR_EXCHANGE, msg);
             return;
         }
-        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv);
+        xseq += 1;
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv + JQ_XHDR);
     };
     auto substitute = [&](int which_out) {
         A.chain0 = my_chain;
@@ -2263,7 +2321,10 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         for (int sidx = 0; sidx < steps; ++sidx) factor_knot(sidx, 0);
         if (sh) exchange(0);
         factor_knot(0, 1);
-        if (hipPeekAtLastError() != hipSuccess) return RBP_ERR_HIP;  // (a launch the device refuses must not pass for a QP that does not converge)
+        if (hipPeekAtLastError() != hipSuccess) {  // (a launch the device refuses must not pass for a QP that does not converge)
+            if (sh && xrc == RBP_OK) poison_peer(1);  // (the peer's next exchange is the forward vector of solve(0))
+            return RBP_ERR_HIP;
+        }
         if (xrc != RBP_OK) return xrc;  // (the peer rank is gone or the exchange hook failed: nothing sensible can follow)
         solve(0);
         JQ_LAUNCH(jq_sweep<PASS_AFF>, dim3(nsw, K), 0, A);

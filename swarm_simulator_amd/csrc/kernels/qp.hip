@@ -2942,7 +2942,7 @@ __device__ int real_roots(const double* cin, int deg, double* out) {
 // |T(k,k-1)| <= eps (|T(k-1,k-1)| + |T(k,k)|), exceptional shifts at local iterations 10 / 30, splitOffTwoRows, eigenvalues read off the
 // quasi-triangular T from the top) is restated here for matrices of order <= 3 -- a documented, deterministic order (include/rbp.h).
 // The Hessenberg reduction is the identity on a companion matrix (its Householder vectors have zero tails) and is left out.
-#pragma clang fp contract(off)  // the order of two nearly symmetric roots can hang on the last bit of a deflation test: same products and sums as oracle/planner.c
+#pragma clang fp contract(off)  // the order of two nearly symmetric roots can hang on the last bit of a deflation test: no fused multiply-adds here, so that a C restatement of the same steps gives the same bits
 #define ES_EPS 2.220446049250313e-16
 #define ES_MIN 2.2250738585072014e-308
 __device__ inline void es_householder(const double* v, int n, double* ess, double& tau, double& beta) {  // Householder.h makeHouseholder

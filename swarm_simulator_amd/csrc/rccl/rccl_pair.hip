@@ -3,8 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 
 #include "rbp_rccl.h"
 
@@ -14,6 +16,8 @@ struct rbp_rccl_pair {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     int device = 0, rank = 0, peer = 0;
+    double timeout_s = 300.0;  // an exchange that does not complete within this many seconds aborts the communicator (<= 0: wait for ever)
+    bool aborted = false;
 };
 
 namespace {
@@ -21,6 +25,15 @@ thread_local std::string g_err;
 int fail(const std::string& what) {
     g_err = what;
     return 1;
+}
+// the pair is unusable after a failed exchange (the two ranks' send / recv sequences no longer match): abort the communicator so that
+// neither this rank nor a peer blocked in the matching receive waits for ever
+int abort_pair(rbp_rccl_pair* p, const std::string& what) {
+    if (p && p->comm && !p->aborted) {
+        (void)ncclCommAbort(p->comm);
+        p->comm = nullptr, p->aborted = true;
+    }
+    return fail(what);
 }
 }  // namespace
 
@@ -62,14 +75,34 @@ int rbp_rccl_pair_create(rbp_rccl_pair** out, int device, int rank, int nranks, 
 int rbp_rccl_exchange(void* pair, void* send_dev, void* recv_dev, size_t bytes) {
     rbp_rccl_pair* p = static_cast<rbp_rccl_pair*>(pair);
     if (!p || !send_dev || !recv_dev) return fail("rbp_rccl_exchange: null argument");
+    if (p->aborted || !p->comm) return fail("rbp_rccl_exchange: the pair's communicator was aborted by an earlier failure");
     if (bytes == 0) return 0;
     ncclResult_t r = ncclGroupStart();
     if (r == ncclSuccess) r = ncclSend(send_dev, bytes, ncclChar, p->peer, p->comm, p->stream);
     if (r == ncclSuccess) r = ncclRecv(recv_dev, bytes, ncclChar, p->peer, p->comm, p->stream);
     const ncclResult_t e = ncclGroupEnd();
     if (r == ncclSuccess) r = e;
-    if (r != ncclSuccess) return fail(std::string("rbp_rccl_exchange: ") + ncclGetErrorString(r));
-    if (hipStreamSynchronize(p->stream) != hipSuccess) return fail("rbp_rccl_exchange: stream synchronisation failed");
+    if (r != ncclSuccess) return abort_pair(p, std::string("rbp_rccl_exchange: ") + ncclGetErrorString(r));
+    // wait for the transfer WITHOUT blocking for ever on a peer that is gone: poll the stream, the communicator's asynchronous error and a
+    // clock; on either, ncclCommAbort -- which also releases a peer blocked in its own receive -- and report failure (rbp_session_run then
+    // returns RBP_ERR_EXCHANGE on this rank; the peer's hook fails the same way: both ranks abort together)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(p->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return abort_pair(p, std::string("rbp_rccl_exchange: stream error: ") + hipGetErrorString(q));
+        ncclResult_t ae = ncclSuccess;
+        if (ncclCommGetAsyncError(p->comm, &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress))
+            return abort_pair(p, std::string("rbp_rccl_exchange: asynchronous communicator error: ") + ncclGetErrorString(ae));
+        if (p->timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > p->timeout_s)
+            return abort_pair(p, "rbp_rccl_exchange: timed out waiting for the peer rank (rbp_rccl_pair_set_timeout)");
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (the first ~ms spins: an exchange is 20 us .. 1 ms)
+    }
+}
+
+int rbp_rccl_pair_set_timeout(rbp_rccl_pair* p, double seconds) {
+    if (!p) return fail("rbp_rccl_pair_set_timeout: null pair");
+    p->timeout_s = seconds;
     return 0;
 }
 

@@ -42,9 +42,10 @@ def _inputs(n, map_ids, mission_file=None, **pkw):
 class _Pair:
     """the exchange between two sessions of one process: each hook posts its send pointer, waits for the peer's, copies device to device"""
 
-    def __init__(self):
+    def __init__(self, corrupt=None):
         import torch
         self.torch = torch
+        self.corrupt = corrupt   # (rank, call index, header word): that rank's copy of the peer's header gets + 1 in that word
         self.barrier = threading.Barrier(2, timeout=120)
         self.posted = [None, None]
         self.calls = [0, 0]
@@ -67,6 +68,8 @@ class _Pair:
                     return 2
                 n = nbytes // 8
                 torch.as_tensor(_View(recv_ptr, n), device="cuda").copy_(torch.as_tensor(_View(peer_ptr, n), device="cuda"))
+                if self.corrupt and self.corrupt[0] == rank and self.corrupt[1] == self.calls[rank]:
+                    torch.as_tensor(_View(recv_ptr, n), device="cuda")[self.corrupt[2]] += 1.0
                 torch.cuda.synchronize()
                 self.barrier.wait()  # (the peer has read my send buffer before the library reuses it)
                 self.calls[rank] += 1
@@ -185,6 +188,34 @@ def test_shard_joint_refusals_and_a_failing_hook():
     assert L.rbp_session_shard_joint(s._h, 0, 2, ok_hook, None) == 0
     assert L.rbp_session_run(s._h, A.RBP_STAGE_PLANNER, None) == A.RBP_ERR_BAD_ARGUMENT
     s.close()
+
+
+@pytest.mark.parametrize("word,name", [(1, "sequence number"), (2, "kind"), (4, "state hash"), (5, "poison word")])
+def test_ranks_that_no_longer_match_are_caught_by_the_exchange_header(word, name):
+    """nothing but replicated state keeps the two ranks' send / recv pairs matched: every exchange carries a header --
+    sequence number, kind, byte count, a hash of the polled state words, a poison word -- that each rank compares with its own.  Here rank 1
+    receives a header that differs in one word at its sixth exchange: it must stop with RBP_ERR_EXCHANGE and say which word, and rank 0 --
+    whose peer is gone -- must come back too (its hook fails), not hang."""
+    p, m, worlds, inits = _inputs(16, [3])
+    pair = _Pair(corrupt=(1, 5, word))
+    sessions = [planner.Session(worlds, [m], p, [inits[0].clone()]) for _ in range(2)]
+    for r, s in enumerate(sessions):
+        assert planner.lib().rbp_session_shard_joint(s._h, r, 2, pair.hooks[r], None) == 0
+    out = [None, None]
+
+    def work(r):
+        rc = planner.lib().rbp_session_run(sessions[r]._h, A.RBP_STAGE_PLANNER, None)
+        out[r] = (rc, planner.last_error())
+        if rc:
+            pair.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=PAIR_TIMEOUT_S) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hung"
+    assert out[1][0] == A.RBP_ERR_EXCHANGE and name in out[1][1] and "diverged" in out[1][1], out
+    assert out[0][0] == A.RBP_ERR_EXCHANGE, out
+    assert pair.calls[1] == 6 and pair.calls[0] <= 7
+    [s.close() for s in sessions]
 
 
 def test_two_rank_process_group_shares_the_joint_solve(tmp_path):

@@ -131,6 +131,31 @@ def test_bench_gpus_flag_spawns_the_ranks():
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
 
 
+def test_eight_rank_gloo_dry_run_of_the_scaling_bench():
+    """what the driver's SCALE run launches at N = 8, on CPU (gloo, --dry-run): `python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8` -- the missions of the sweep shard over eight ranks (disjoint slices, weak scaling), n_gpus is the real world size, the
+    aggregate counts every rank's agents; and `--config c4`: 256 agents in eight contiguous slices, ONE fused all-gather gives every rank
+    the whole corridor (bytes only: the sign of a zero normal survives); with --joint the ranks form the pairs {2k, 2k+1}"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1"]
+
+    def run(extra):
+        out = subprocess.run(base + ["--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run"] + extra,
+                             capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    res = run(["--missions-per-gpu", "7"])
+    assert res["n_gpus"] == 8 and res["agents_all_ranks"] == 8 * 7 * 64 and res["maps_rank0"] == [1, 2, 3, 4]
+    maps = [bench.shard_missions(7, r, 8) for r in range(8)]
+    assert sorted(m for s in maps for m in s) == [1 + i % 50 for i in range(56)] or len({m for s in maps for m in s}) == 50
+    res = run(["--config", "c4", "--joint"])
+    assert res["n_gpus"] == 8 and res["c4_gather_ok_on_every_rank"] is True and res["c4_joint_rank_pairs"] is True
+    sl = res["c4_agent_slices"]
+    assert len(sl) == 8 and sl[0][0] == 0 and sl[-1][1] == 256 and all(e - b == 32 for b, e in sl)
+
+
 def test_four_rank_gloo_pair_groups(tmp_path):
     """the rank pairs that share a joint factorisation (sharded.pair_group; rbp_session_shard_joint): with four ranks {0, 1} and {2, 3},
     every rank taking part in the creation of every pair's group; an odd world has no pairs (the solve is then replicated)."""
