@@ -2563,7 +2563,7 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
             __syncthreads();
             PROF(0);
 #ifdef QP_POLSTATS
-            if (tid == 0 && !polish_first) scal[25] += (early_tries == 1), scal[26] += (early_tries == 1 && acc == 0), scal[27] += (early_tries == 2), scal[29] += (early_tries == 2 && acc == 0);  // (tools/r05_polstats.py)
+            if (tid == 0 && !polish_first) scal[25] += (early_tries == 1), scal[26] += (early_tries == 1 && acc == 0), scal[27] += (early_tries == 2), scal[29] += (early_tries == 2 && acc == 0);  // (tools/experiments/r05_polstats.py)
 #endif
             if (acc == 0) {
                 ok = true, polished = 1;

@@ -4,7 +4,7 @@
 #   part "joint":  joint QP bench lines (200 / 50 resident), kernel trace of the 200-mission step, MFMA + SQ counters, lone missions
 #   part "other":  the other BASELINE configurations
 #   part "tests":  pytest -m gpu
-# usage: tools/r05_collect.sh [bench] [joint] [other] [tests]
+# usage: tools/experiments/r05_collect.sh [bench] [joint] [other] [tests]
 set -u
 OUT=$PWD/gpurun_out/r05; mkdir -p $OUT; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -58,7 +58,7 @@ joint)
   KL="jq_update_bulk|jq_update|jq_panel|jq_pivot0|jq_mv|jq_prep|jq_sweep"
   { agg $OUT/jpmc "$KL"; echo "---- HBM side, KB per dispatch as reported (FETCH_SIZE counts half of the bytes of wide reads on gfx950: MI355X_MICROARCH.md)"; agg $OUT/jpmc_FETCH_SIZE "$KL"; agg $OUT/jpmc_WRITE_SIZE "$KL"; } > $OUT/joint_pmc.txt 2>&1
   rm -rf $OUT/jkt $OUT/jpmc $OUT/jpmc_FETCH_SIZE $OUT/jpmc_WRITE_SIZE
-  timeout 600 python tools/r05_joint_async_ab.py > $OUT/joint_async_ab.txt 2>&1 < /dev/null
+  timeout 600 python tools/experiments/r05_joint_async_ab.py > $OUT/joint_async_ab.txt 2>&1 < /dev/null
   for cfg in "64 3" "256 1"; do set -- $cfg; timeout 600 python tools/gpu_joint_wide.py $1 $2 --no-wg --reps 3 > $OUT/joint_single_$1.log 2>&1 < /dev/null; done
   ;;
 other) bash tools/collect_other_configs.sh r05 > /dev/null 2>&1 ;;

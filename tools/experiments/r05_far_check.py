@@ -1,6 +1,6 @@
 """Developer tool (GPU box): the reduced row set of the interior-point phase (QP_FAR_SLACK builds, RBP_HIP_LIB) on the 50-map sweep:
 control points against the library's default build (every row near), iterations, algorithmic bytes, batch QPs solved twice.
-usage: RBP_HIP_LIB=... python tools/r05_far_check.py <ref.npy | --write ref.npy>"""
+usage: RBP_HIP_LIB=... python tools/experiments/r05_far_check.py <ref.npy | --write ref.npy>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench

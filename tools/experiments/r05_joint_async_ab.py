@@ -1,6 +1,6 @@
 """rbp_session_run_async on the 50-map joint sweep (64 agents): one session / two sessions of 25 missions in flight at once / four of
 12-13.  A session's host loop synchronises once per interior-point round; with several sessions in flight one session's kernels fill the
-other's synchronisation gaps.  Run on a GPU box from the repo root:   python tools/r05_joint_async_ab.py [agents]"""
+other's synchronisation gaps.  Run on a GPU box from the repo root:   python tools/experiments/r05_joint_async_ab.py [agents]"""
 import os
 import sys
 import time

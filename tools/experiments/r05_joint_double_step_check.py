@@ -1,5 +1,5 @@
 """the double-step tile sweep (joint_schedule 3) against the one-pivot bulk schedule (2) and the look-ahead schedule (1), one mission each:
-control points, objective, iterations.  python tools/r05_joint_double_step_check.py"""
+control points, objective, iterations.  python tools/experiments/r05_joint_double_step_check.py"""
 import os
 import sys
 

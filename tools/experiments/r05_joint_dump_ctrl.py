@@ -1,6 +1,6 @@
 """Developer tool (GPU box): control points of JOINT missions (plan/sequential = false) through the library RBP_HIP_LIB names -> <out>.npy, to
 compare two builds of kernels/jqp.hip bit for bit.  Cases: 64 agents x maps 1..6 in one session (look-ahead launches of many tiles), one
-64-agent, one 32-agent and one 16-agent mission alone (fused-panel launches).  usage: python tools/r05_joint_dump_ctrl.py <out>"""
+64-agent, one 32-agent and one 16-agent mission alone (fused-panel launches).  usage: python tools/experiments/r05_joint_dump_ctrl.py <out>"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench

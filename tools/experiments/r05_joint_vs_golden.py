@@ -1,5 +1,5 @@
 """Developer tool (GPU box): the grid-wide joint solver against committed oracle vectors, case by case.
-usage: python tools/r05_joint_vs_golden.py [--schedule=N] <npz> [<npz> ...]     (joint64_sweep.npz | joint32_sweep.npz | joint_heldout.npz)"""
+usage: python tools/experiments/r05_joint_vs_golden.py [--schedule=N] <npz> [<npz> ...]     (joint64_sweep.npz | joint32_sweep.npz | joint_heldout.npz)"""
 import hashlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 """Developer tool (GPU box): the phase-split schedule of the batch QPs (kernels/qp_phase.inc, rbp_solver_opts.qp_schedule = 2) against one workgroup
 per mission (qp_schedule = 1) on the same missions: status, polish counts, control points, cost, iterations; then wall time of both at
-K resident missions.   usage: python tools/r05_phase_check.py [K] [agents] [batch] [iteration]"""
+K resident missions.   usage: python tools/experiments/r05_phase_check.py [K] [agents] [batch] [iteration]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
