@@ -73,6 +73,9 @@
 #ifndef QP_NBHD_GAMMA
 #define QP_NBHD_GAMMA 1e-3  // wide neighbourhood: no complementarity product below gamma * mu
 #endif
+#ifndef QP_NBHD_BACKOFF
+#define QP_NBHD_BACKOFF 0.8  // a step the wide-neighbourhood test refuses is repeated with this fraction of its length
+#endif
 #ifndef QP_STEP_FRAC
 #define QP_STEP_FRAC 0.997  // fraction of the step to the boundary (A/B on one box: 0.98 +5 %, 0.99 +1.4 %, 0.997 and 0.999 best, 0.9999 +20 % time)
 #endif
@@ -2675,7 +2678,7 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
             __threadfence_block();
             __syncthreads();
             if (pmin >= QP_NBHD_GAMMA * gap_next / nrows_free) break;
-            alpha *= 0.8;
+            alpha *= QP_NBHD_BACKOFF;
         }
         // the new state becomes the current one
         {

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): control points of K missions of the headline workload through the library RBP_HIP_LIB names -> <out>.npy
 (two libraries that must agree bit for bit: run twice, compare with numpy).  usage: python tools/experiments/r05_dump_ctrl.py <out> [K]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bench
 from swarm_simulator_amd import planner
 from swarm_simulator_amd.types import Param

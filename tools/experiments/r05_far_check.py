@@ -2,7 +2,7 @@
 control points against the library's default build (every row near), iterations, algorithmic bytes, batch QPs solved twice.
 usage: RBP_HIP_LIB=... python tools/experiments/r05_far_check.py <ref.npy | --write ref.npy>"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bench
 from swarm_simulator_amd import planner
 from swarm_simulator_amd.types import Param

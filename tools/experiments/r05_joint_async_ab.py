@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 from swarm_simulator_amd import _abi as A  # noqa: E402
 from swarm_simulator_amd import planner  # noqa: E402

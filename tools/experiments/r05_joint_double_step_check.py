@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from swarm_simulator_amd import host, planner  # noqa: E402
 from swarm_simulator_amd.types import Param  # noqa: E402
 

@@ -2,7 +2,7 @@
 compare two builds of kernels/jqp.hip bit for bit.  Cases: 64 agents x maps 1..6 in one session (look-ahead launches of many tiles), one
 64-agent, one 32-agent and one 16-agent mission alone (fused-panel launches).  usage: python tools/experiments/r05_joint_dump_ctrl.py <out>"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, bench
 from swarm_simulator_amd import planner
 from swarm_simulator_amd.types import Param

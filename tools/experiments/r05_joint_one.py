@@ -1,7 +1,7 @@
 """Developer tool (GPU box): ONE joint mission (mission file, world file), e.g. with the developer library and RBP_JOINT_TRACE=1:
 RBP_HIP_LIB=$PWD/swarm_simulator_amd/lib/librbp_hip_dev.so RBP_JOINT_TRACE=1 python tools/experiments/r05_joint_one.py mission_64agents_20.json map19.bt"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from swarm_simulator_amd import host, planner
 from swarm_simulator_amd.types import Param
 p = Param.test_sweep(sequential=False)

@@ -2,13 +2,13 @@
 usage: python tools/experiments/r05_joint_vs_golden.py [--schedule=N] <npz> [<npz> ...]     (joint64_sweep.npz | joint32_sweep.npz | joint_heldout.npz)"""
 import hashlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from swarm_simulator_amd import _abi as A
 from swarm_simulator_amd import host, planner
 from swarm_simulator_amd.types import Param
 from tests import oracle_lib as O
 
-GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 p = Param.test_sweep(sequential=False)
 SCHED = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--schedule=")), 0)
 for name in [a for a in sys.argv[1:] if not a.startswith("--")]:

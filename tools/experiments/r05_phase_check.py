@@ -3,7 +3,7 @@ per mission (qp_schedule = 1) on the same missions: status, polish counts, contr
 K resident missions.   usage: python tools/experiments/r05_phase_check.py [K] [agents] [batch] [iteration]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from swarm_simulator_amd import _abi as A
 from swarm_simulator_amd import host, planner
