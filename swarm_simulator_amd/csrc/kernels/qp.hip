@@ -1030,6 +1030,95 @@ __device__ __forceinline__ void assemble_knots_lds(const AsmArgs& A, double* scr
         kl_sync();
     }
 }
+// ---- just-in-time assembly by the chains' companion waves (256-thread build, round 6; see twisted_factor ROLE 2) --------------------------
+// Two out-of-line steps per block, so that the companion's column loop keeps its registers and its stack frame to itself:
+//   fasm_fetch   the block's inputs -- weight sums of its six control points per batch agent, pair weights, the pairs' normals -- travel from
+//                global memory into the wave's LDS scratch by global_load_lds (4 bytes per lane and instruction, no registers, nobody waits):
+//                issued right after the PREVIOUS block's tiles, they land while the companion follows that block's factorisation;
+//   fasm_tiles   the 3 x 3 tiles from the LDS inputs into the symmetric LDS image the chain reads (the arithmetic of assemble_knots_lds).
+// Scratch layout as in assemble_knots_lds (image | Sin | Pw | Nr), except that Nr holds the normals as the floats they are.
+__device__ __forceinline__ AsmArgs uni(const AsmArgs& A);  // (arguments of a non-kernel function arrive in vector registers: see BlkArgs)
+template <class T>
+__device__ __forceinline__ T* uni(T* p);
+__device__ __noinline__ void fasm_fetch(AsmArgs Av, double* scratch_v, int jv) {
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    typedef __attribute__((address_space(3))) char lchar;
+    const AsmArgs A = uni(Av);
+    double* scratch = uni(scratch_v);
+    const int j = __builtin_amdgcn_readfirstlane(jv);
+    const int nb = A.nb, oq = A.oq, nk = 9 * nb, npb = nb * (nb - 1) / 2, lane = threadIdx.x & 63, j60 = 6 * j + 3;
+    const size_t ncp = (size_t)nb * oq;
+    lchar* Sin = (lchar*)((kl_lds*)scratch + nk * KL_LD);
+    lchar* Pw = Sin + (size_t)nb * 36 * 8;
+    lchar* Nr = Pw + (size_t)6 * npb * 8;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the previous block's tiles have read their inputs)
+    for (int c = 0; c * 64 < nb * 72; ++c) {  // Sin[a][sym][p], 8 bytes each, as dwords
+        const int dw = c * 64 + lane, idx = dw >> 1, a = idx / 36, e = (idx / 6) % 6, pp = idx % 6;
+        if (dw < nb * 72)
+            __builtin_amdgcn_global_load_lds((gvoid*)((const unsigned*)(A.cpacc + (size_t)e * ncp + (size_t)a * oq + j60 + pp) + (dw & 1)), (lvoid*)(Sin + c * 256), 4, 0, 0);
+    }
+    for (int c = 0; c * 64 < npb * 12; ++c) {  // Pw[pair][p]
+        const int dw = c * 64 + lane, idx = dw >> 1;
+        if (dw < npb * 12)
+            __builtin_amdgcn_global_load_lds((gvoid*)((const unsigned*)(A.pwgt + (size_t)(idx / 6) * oq + j60 + idx % 6) + (dw & 1)), (lvoid*)(Pw + c * 256), 4, 0, 0);
+    }
+    if (lane < 6 * npb) {  // Nr[pair][left / right segment][3] (floats)
+        const int pw = lane / 6, sg = (lane / 3) % 2, c3 = lane % 3;
+        int lo = 0, rest = pw;  // pair pw = (lo, hi) in the order lo * nb - lo (lo + 1) / 2 + (hi - lo - 1)
+        while (rest >= nb - 1 - lo) rest -= nb - 1 - lo, lo++;
+        const int hi = lo + 1 + rest;
+        const size_t off = (pair_index(A.N, A.first + lo, A.first + hi) * A.M + sg + j) * 3 + c3;
+        __builtin_amdgcn_global_load_lds((gvoid*)(A.normals + off), (lvoid*)Nr, 4, 0, 0);
+    }
+}
+__device__ __noinline__ void fasm_tiles(AsmArgs Av, double* scratch_v, int jv) {
+    const AsmArgs A = uni(Av);
+    double* scratch = uni(scratch_v);
+    const int j = __builtin_amdgcn_readfirstlane(jv);
+    const int nb = A.nb, nk = 9 * nb, npb = nb * (nb - 1) / 2, n3 = 3 * nb, per = n3 * (n3 + 1) / 2, lane = threadIdx.x & 63, jn = j + 1;
+    kl_lds* Timg = (kl_lds*)scratch;
+    const kl_lds* Sin = Timg + nk * KL_LD;
+    const kl_lds* Pw = Sin + nb * 36;
+    const __attribute__((address_space(3))) float* Nr = (const __attribute__((address_space(3))) float*)(Pw + 6 * npb);
+    double L[9], Dk[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L[e] = A.Lk[9 * jn + e], Dk[e] = A.Dk[9 * jn + e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the inputs have landed (fasm_fetch was issued a block ago: nothing to wait for)
+    kl_sync();
+    for (int u = 0; u * 64 < per; ++u) {
+        const int t = lane + 64 * u;
+        if (t < per) {
+            int Ai = (int)(((2 * n3 + 1) - sqrtf((float)((2 * n3 + 1) * (2 * n3 + 1) - 8 * t))) * 0.5f);
+            if (Ai * n3 - Ai * (Ai - 1) / 2 > t) Ai--;
+            if ((Ai + 1) * n3 - (Ai + 1) * Ai / 2 <= t) Ai++;
+            const int Bi = Ai + t - (Ai * n3 - Ai * (Ai - 1) / 2);
+            const int a = Ai / 3, k = Ai % 3, b = Bi / 3, l = Bi % 3;
+            double Sv[6];
+            if (a == b) {
+                const int kk = k < l ? k : l, ll = k < l ? l : k, sym = kk == 0 ? ll : (kk == 1 ? 2 + ll : 5);
+#pragma unroll
+                for (int pp = 0; pp < 6; ++pp) Sv[pp] = Sin[(a * 6 + sym) * 6 + pp];
+            } else {  // a < b
+                const int pw = a * nb - a * (a + 1) / 2 + (b - a - 1);
+#pragma unroll
+                for (int pp = 0; pp < 6; ++pp)
+                    Sv[pp] = -Pw[pw * 6 + pp] * (double)Nr[(pw * 2 + (pp >= 3)) * 3 + k] * (double)Nr[(pw * 2 + (pp >= 3)) * 3 + l];
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    double acc = Sv[0] * L[e] * L[f] + Sv[1] * L[3 + e] * L[3 + f] + Sv[2] * L[6 + e] * L[6 + f];
+                    if (e == f) acc += Sv[3 + e];
+                    if (Ai == Bi) acc += Dk[3 * e + f];
+                    Timg[(3 * Ai + e) * KL_LD + 3 * Bi + f] = acc;
+                    Timg[(3 * Bi + f) * KL_LD + 3 * Ai + e] = acc;
+                }
+        }
+    }
+    kl_sync();
+}
 // all knots up front, one wave per knot in turn (256-thread build).  lds: QP_THREADS / 64 scratch areas.
 __device__ void assemble_blocks_lds(const AsmArgs& A, int nj, double* lds) {
     const int wave = threadIdx.x >> 6, NW = QP_THREADS / 64;
@@ -1097,6 +1186,15 @@ __device__ __forceinline__ int twist_mid(int nj) { return nj / 2; }
 // through the LDS: assemble_knots_lds); the 256-thread build assembles all blocks up front (assemble_blocks_lds).
 #define ASM_WAVE0 4                                                        // first assembling wave
 #define ASM_HELPERS (QP_THREADS / 64 > ASM_WAVE0 ? QP_THREADS / 64 - ASM_WAVE0 : 0)   // assembling waves
+// (round 6) 256-thread build: no waves to spare for the assembly -- but the two COMPANION waves (M = L^-T behind the chains) idle between
+// the end of one block's factorisation and the start of the next (while the chain forms the coupling rows and the rank-36 update): each
+// assembles its chain's NEXT block into an LDS image in that gap, just in time, and the chain reads it from there (the Timg path of the
+// 512-thread build).  The up-front assembly phase -- 11 % of a mission's time under load, most of it spent waiting for its own loads and
+// stores: profiles/r06_ab_qp_levers.txt -- and the round trip of every T_j through global memory disappear.
+#ifndef QP_FOLLOW_ASM
+#define QP_FOLLOW_ASM (ASM_HELPERS == 0)
+#endif
+#define ASMF_READY(cnt, h) ((kl_ldsi*)((cnt) + 76 + (h)))  // images the companion of chain h has finished (monotone over a factorisation)
 __device__ __forceinline__ void wait_blocks(int* cnt, int i) {
     while (__hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ASM_HELPERS) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1194,6 +1292,9 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
     kl_store_rows<NK>(m, MX, r, act);
     if (FOLLOW) kl_publish(Mdone, done_value);
     double* Mg = w.Lf + (size_t)j * KF_STRIDE(NK);
+    // (256-thread build: the next block's inputs, sent for a block ago by global_load_lds, are counted on this wave's memory counter; they have
+    // long landed -- drain the counter HERE, so that the tiles' wait for them does not have to wait for the row stores below as well)
+    if (FOLLOW && QP_FOLLOW_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (act) {  // row r of M_j and 1 / d_j -> QpWs::Lf (16 bytes per lane and store instruction: the store path of a CU is issue bound)
         double* row = Mg + (size_t)r * NK;
         if ((NK & 1) == 0) {
@@ -1242,17 +1343,23 @@ __device__ __forceinline__ bool wave_factor_chain(const QpDims& d, const QpWs& w
     const bool act = r < NK;
     const int rr = act ? r : 0;
     bool ok = true;
-    int seen = 0;
+    int seen = 0, seen_img = 0;
     for (int i = 0, j = j0; i < count; ++i, j += dir) {
         CHAIN_T0;
         if (i > 0) kl_syrk<NK>(MX, I, U, r, false);
         CHAIN_T(25);
-        wait_blocks(cnt, i);
+        if (QP_FOLLOW_ASM)
+            kl_await(ASMF_READY(cnt, h), i + 1, seen_img);  // the companion wave's image of this block
+        else
+            wait_blocks(cnt, i);
         CHAIN_T(26);
         double e0, e1, e2, x[NK];
         coupling_coef(w, j, dir, rr, e0, e1, e2);  // (issued here: three loads from the L2, ~1 us under load, needed after the factorisation)
         // (512-thread build: T_j from the LDS image of the assembling wave (side h, parity of the step), see twisted_factor)
-        const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsW - (size_t)h * A::SIZE + 2 * A::SIZE + 128 + (size_t)(h + 2 * (i & 1)) * ASML_DOUBLES(NK, (NK / 9))) : nullptr;
+        // (256-thread build: from the ONE image of the chain's companion wave, see twisted_factor ROLE 2)
+        const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsW - (size_t)h * A::SIZE + 2 * A::SIZE + 128 + (size_t)(h + 2 * (i & 1)) * ASML_DOUBLES(NK, (NK / 9)))
+                             : QP_FOLLOW_ASM ? (const kl_lds*)(ldsW - (size_t)h * A::SIZE + 2 * A::SIZE + 128 + (size_t)h * ASML_DOUBLES(NK, (NK / 9)))
+                                             : nullptr;
         if (!knot_ldl<NK>(w, j, i > 0, base, r, act, rr, P, i * (NK + 1), Timg, ASM_CONSUMED(cnt, h), i + 1)) ok = false;
         kl_await(Mdone, i + 1, seen);
         kl_coupling_rows<NK>(x, MX, r, act, e0, e1, e2);
@@ -1272,13 +1379,19 @@ __device__ __forceinline__ bool wave_factor_mid(const QpDims& d, const QpWs& w, 
     int nsy = 0;
     if (mid > 0) kl_syrk<NK>(bl + A::MX, bl + A::I, bl + A::C, r, false), nsy++;
     if (mid + 1 < d.nj) kl_syrk<NK>(br + A::MX, br + A::I, bl + A::C, r, nsy > 0), nsy++;
-    wait_blocks(cnt, cnt_idx);
+    if (QP_FOLLOW_ASM) {
+        int seen_img = 0;
+        kl_await(ASMF_READY(cnt, 0), mid + 1, seen_img);  // the left chain's companion makes the middle block after the chain's mid blocks
+    } else {
+        wait_blocks(cnt, cnt_idx);
+    }
     // progress words of the middle block.  512-thread build: its M is computed by the left chain's companion wave, like every other
     // block's (twisted_factor, ROLE 2) -- on the chain wave it is ~10 k cycles more at the end of every factorisation: one mission
     // 122.4 -> 121.1 ms.  With two workgroups per CU the polling companion costs the neighbour more than it saves (-1.3 % at 2000
     // resident, A/B on one box): the 256-thread build keeps M on the chain wave.
     kl_ldsi* scratch = CHAIN_SYNC(cnt, 2);
-    const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsL + 2 * A::SIZE + 128 + (size_t)(2 * (cnt_idx & 1)) * ASML_DOUBLES(NK, (NK / 9))) : nullptr;
+    const kl_lds* Timg = ASM_HELPERS > 0 ? (const kl_lds*)(ldsL + 2 * A::SIZE + 128 + (size_t)(2 * (cnt_idx & 1)) * ASML_DOUBLES(NK, (NK / 9)))
+                         : QP_FOLLOW_ASM ? (const kl_lds*)(ldsL + 2 * A::SIZE + 128) : nullptr;
     const bool ok = knot_ldl<NK>(w, mid, nsy > 0, bl, r, act, rr, scratch, 0, Timg);
     if (!QP_MID_FOLLOW) {
         int seen = 0;
@@ -1354,7 +1467,34 @@ __device__ __forceinline__ bool twisted_factor(const QpDims& d, const QpWs& w, i
         kl_ldsi *P = CHAIN_SYNC(cnt, wave), *Mdone = P + 1;
         const int r = threadIdx.x & 63;
         int seen = 0;
-        for (int i = 0; i < count; ++i) knot_inverse<NK, true>(w, j0 + i * dir, base, r, r < NK, P, i * (NK + 1), seen, Mdone, i + 1);
+        if (QP_FOLLOW_ASM) {
+            // ... and the chain's blocks, assembled just in time: block n + 1 right after the companion work of block n, while the chain
+            // forms the coupling rows and the rank-NK update; the left chain's companion makes the MIDDLE block last.  One image per chain:
+            // the chain read block n out of it at the start of its factorisation (ASM_CONSUMED), long before block n + 1 is written.
+            const AsmArgs A = *asmb;
+            double* scratch = lds + 2 * AREA + 128 + (size_t)wave * ASML_DOUBLES(NK, (NK / 9));
+            kl_ldsi *ready = ASMF_READY(cnt, wave), *consumed = ASM_CONSUMED(cnt, wave);
+            const int total = count + (wave == 0 ? 1 : 0);
+            int seen_c = 0;
+            auto blk = [&](int n) { return n < count ? j0 + n * dir : mid; };
+            auto make = [&](int n) {  // block n's inputs are in the scratch (fetched a block ago): its tiles, then the fetch of block n + 1
+                if (n > 0) kl_await(consumed, n, seen_c);
+                fasm_tiles(A, scratch, blk(n));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                kl_publish(ready, n + 1);
+                if (n + 1 < total) fasm_fetch(A, scratch, blk(n + 1));
+            };
+            if (total > 0) {
+                fasm_fetch(A, scratch, blk(0));
+                make(0);
+            }
+            for (int i = 0; i < count; ++i) {
+                knot_inverse<NK, true>(w, j0 + i * dir, base, r, r < NK, P, i * (NK + 1), seen, Mdone, i + 1);
+                if (i + 1 < total) make(i + 1);
+            }
+        } else {
+            for (int i = 0; i < count; ++i) knot_inverse<NK, true>(w, j0 + i * dir, base, r, r < NK, P, i * (NK + 1), seen, Mdone, i + 1);
+        }
     }
     if (!ok && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
     __threadfence_block();
@@ -2578,8 +2718,8 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
         // waves to spare (two chains, two companions) and assembles up front with all of them
         if (d.nk > 36)
             assemble_blocks(c, lds);
-        else if (ASM_HELPERS == 0)
-            assemble_blocks_lds(asm_args(c), d.nj, lds);
+        else if (ASM_HELPERS == 0 && !QP_FOLLOW_ASM)
+            assemble_blocks_lds(asm_args(c), d.nj, lds);  // (256-thread build, round 6: the chains' companion waves assemble just in time instead)  // (256-thread build, round 6: the chains' companion waves assemble just in time instead)
         PROF(3);
         __threadfence_block();
         __syncthreads();
@@ -2776,6 +2916,17 @@ __device__ void restore_dummy(const DevSession& s, int mission, int first, int n
 // The REST of a mission's schedule from batch (it0, l0) on, whose first attempt on the reduced row set failed (see qp_batch_kernel): that batch
 // again with every row, then the remaining batches and passes.  Sg: the kernel's copy of the session struct in LDS (the body was written for a
 // struct that lives in registers: it gets a private copy).
+// ONE batch QP out of line.  (round 6) The rest-of-schedule function below used to inline the body inside its loops; with the body's calls
+// compiled under interprocedural register allocation, a value the compiler had hoisted out of those loops into a vector register came back
+// from a FAILED factorisation (the early way out of the interior-point loop) with the callee's leftovers in some lanes, and the next
+// attempt computed addresses from it (memory fault in rbase_from_acc, found with rocgdb; -mllvm -enable-ipra=0 made it disappear at -6 % of
+// the bench).  A call per batch QP gives every attempt a fresh frame: nothing of one attempt's register state reaches the next.  This path
+// runs for ~1 batch QP in 800; its speed does not matter.
+__device__ __noinline__ int qp_batch_body_outofline(const DevSession* Sg, double* ws_base, size_t ws_stride, int mission, int batch, int nbmax,
+                                                    int reset_cost, int lds_doubles, int pass_index, double far_R) {
+    const DevSession S = *Sg;
+    return qp_batch_body(S, uni(ws_base), ws_stride, uni(mission), uni(batch), uni(nbmax), uni(reset_cost), uni(lds_doubles), uni(pass_index), far_R);
+}
 __device__ __noinline__ void qp_finish_schedule(const DevSession* Sg, double* ws_base, size_t ws_stride, int mission, int passes, int biter, int nbmax,
                                                int lds_doubles, int it0, int l0) {
     const DevSession S = *Sg;
@@ -2794,7 +2945,7 @@ __device__ __noinline__ void qp_finish_schedule(const DevSession* Sg, double* ws
                     __syncthreads();
                 }
                 const double far_R = (attempt == 0 && it == 0 && S.p.polish && S.p.far_slack > 0.0) ? S.p.far_slack : 1e300;
-                const int again = uni(qp_batch_body(S, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R));
+                const int again = uni(qp_batch_body_outofline(Sg, ws_base, ws_stride, mission, l, nbmax, (int)(l == 0), lds_doubles, it, far_R));
                 __threadfence_block();
                 __syncthreads();
                 if (!again) break;
@@ -3300,7 +3451,8 @@ static size_t qp_lds_bytes(int bs, int M) {
     lds = std::max(lds, sizeof(double) * (size_t)(std::max(polish_lds_doubles(nk), polish_lds_doubles(nkw)) + 18 * (M - 1) + 32) + 16);
     lds = std::max(lds, sizeof(double) * (16 + (size_t)QP_STAGE_BUFS * 2 * (nkw * KL_LD + KL_I) + (size_t)(M - 1) * nkw + 2 + 6 * KS_VLEN + 2 * 64 + 64));  // solve_staged
     // chain areas + assembly progress counters (+ the assembling waves' LDS scratch in the 512-thread build)
-    lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + ASM_HELPERS * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
+    // (256-thread build: the two companion waves' images of the just-in-time assembly)
+    lds = std::max(lds, sizeof(double) * (size_t)(2 * kl_area_doubles(nkw) + 128 + (QP_FOLLOW_ASM ? 2 : ASM_HELPERS) * ASML_DOUBLES(nkw, nkw / 9) + 32) + 16);
     if (nk > 36 && nk <= 72) {  // LDS-resident tiled path: three blocks of a knot (leading dimension + 2)
         const size_t lb = (size_t)((nk + 15) & ~15);
         lds = std::max(lds, sizeof(double) * (3 * lb * (lb + 2) + 34) + 16);

@@ -67,15 +67,27 @@ def test_reduced_row_set_is_the_same_optimum_for_any_radius():
     end polished on the reduced set is solved again with every row.  Off, the default 0.7 m, and 0.15 m -- where so many needed rows are
     left out that second attempts actually happen (scalars slot 11 counts them) -- must give the same KKT-certified optimum, feasible for
     every row of the reference's constraint sets."""
+    _reduced_row_set_case(0)
+
+
+def test_reduced_row_set_second_attempts_in_the_256_thread_build():
+    """the same with the throughput build of the QP kernel pinned (rbp_solver_opts.qp_variant = 4: what a session of more missions than CUs
+    runs; small sessions default to the 512-thread build, so nothing else in the suite sends second attempts through it).  Round 6: its
+    rest-of-schedule path read a vector register that a failed factorisation had left dirty -- a memory fault, seen only once the kernel's
+    register allocation had shifted (the just-in-time block assembly) -- and now runs every batch QP of that path in a frame of its own."""
+    _reduced_row_set_case(4)
+
+
+def _reduced_row_set_case(variant):
     p = Param.test_sweep()
     m = host.load_mission("mission_64agents_15.json")
-    maps = [1, 13, 27, 46]
+    maps = [1, 13, 27, 46] if variant == 0 else [1, 21]
     worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
     inits = [host.ecbs_plan(w, m, p) for w in worlds]
     res, again = {}, {}
     for R in (0.0, 0.7, 0.15):
         plans = [g.clone_inputs() for g in inits]
-        sess = planner.Session(worlds, [m] * len(maps), p, plans, opts=planner.solver_opts(qp_schedule=1, qp_far_slack=R))
+        sess = planner.Session(worlds, [m] * len(maps), p, plans, opts=planner.solver_opts(qp_schedule=1, qp_variant=variant, qp_far_slack=R))
         sess.run(A.RBP_STAGE_ALL)
         assert sess.download() == [0] * len(maps)
         again[R] = sess.scalars(12)[:, 11].sum()
