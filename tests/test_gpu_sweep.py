@@ -170,7 +170,7 @@ def test_both_builds_of_the_qp_kernel_need_the_same_work_on_the_sweep():
     it2, it4 = (sum(g.qp_iterations for g in res[v]) for v in (2, 4))
     print(f"\ninterior-point iterations on the 50 maps: 512-thread build {it2}, 256-thread build {it4}")
     assert abs(it2 - it4) <= 0.003 * it4, (it2, it4)
-    assert abs(it2 - 12768) <= 40 and abs(it4 - 12773) <= 40, (it2, it4)   # (recorded for the round-6 sources; a change of the solver moves both)
+    assert abs(it2 - 12776) <= 40 and abs(it4 - 12769) <= 40, (it2, it4)   # (recorded for the round-6 sources; a change of the solver moves both)
     worst = max(float(np.abs(a.ctrl - b.ctrl).max()) for a, b in zip(res[2], res[4]))
     assert worst < 1e-6, worst
 
