@@ -42,7 +42,7 @@ CONFIGS = {  # BASELINE.json configs -> flags (C1 is the CPU plumbing case of th
 }
 
 
-PMC_FILE = "profiles/r05_pmc.json"   # HBM-side bytes per launch, collected by tools/collect_profiles.sh on the sources hashed below
+PMC_FILE = "profiles/r06_pmc.json"   # HBM-side bytes per launch, collected by tools/collect_profiles.sh on the sources hashed below
 
 
 def kernel_source_sha(variant="auto"):
@@ -283,7 +283,7 @@ def joint_leg(agents=64):
             "note": "whole planner stage of 50 resident 64-agent joint missions (sweeps, factorisations, substitutions, polish): a lower bound "
                     "of the update kernel's own rate, which kernel_profiled carries"}
     try:
-        jk = json.load(open(os.path.join(ROOT, "profiles", "r05_joint_kernel.json")))
+        jk = json.load(open(os.path.join(ROOT, "profiles", "r06_joint_kernel.json")))
         base = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
         h = hashlib.sha256()
         for f in sorted(os.listdir(base)):
@@ -292,7 +292,13 @@ def joint_leg(agents=64):
         if jk["joint_source_sha"] == h.hexdigest()[:16]:
             roof["kernel_profiled"] = {"kernel": jk["kernel"], "achieved": jk["tflops"], "unit": "TFLOP/s", "frac": jk["frac_of_fp64_mfma_peak"],
                                        "share_of_logged_flops": jk["share_of_logged_flops_in_this_kernel"], "missions_per_gpu": jk["missions_per_gpu"],
-                                       "source": "profiles/r05_joint_kernel.json"}
+                                       "source": "profiles/r06_joint_kernel.json"}
+            # HBM-side bytes per launch of that kernel (FETCH_SIZE / WRITE_SIZE passes of the same command, gfx950 correction applied by
+            # tools/joint_kernel_json.py): a committed constant tied to the joint solver's sources by the hash above, like traffic_profiled
+            if jk.get("traffic"):
+                roof["traffic"] = jk["traffic"]["hbm_bytes_per_launch"]
+                roof["traffic_note"] = (f"per launch of {jk['kernel']} at {jk['missions_per_gpu']} resident missions (profiled constant, "
+                                        "profiles/r06_joint_kernel.json); this run's sweep keeps 50 resident")
     except Exception:
         pass
     return {"joint_single_mission_ms": single["two_calls_ms"], "joint_single_mission": single,
@@ -366,6 +372,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-mission latency leg (profiling runs: keeps the kernel list clean)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU test of the launcher)")
     ap.add_argument("--dry-run", action="store_true", help="launcher test: initialise the ranks, print the JSON skeleton, plan nothing")
+    ap.add_argument("--native-pair", action="store_true",
+                    help="--config c4 --joint on an even number of ranks: every rank runs lib/rbp_c4_joint_rank (plain C++ on the C ABIs: no Python, no torch "
+                         "in the solve's process) and the rank pairs {2k, 2k+1} share the joint solve through the STREAM-ORDERED RCCL exchange of "
+                         "lib/librbp_rccl.so; torch.distributed only collects the ranks' times")
     args = ap.parse_args()
     if args.config:
         for k, v in CONFIGS[args.config].items():
@@ -415,6 +425,8 @@ def main():
 
     pkw = dict(batch_size=args.batch_size, iteration=args.iteration, sequential=not args.joint)
     param = Param.test_sweep(**pkw)
+    if args.config == "c4" and args.native_pair and args.joint:
+        return bench_c4_native(args, rank, n_ranks, local_rank, dist)
     if args.config == "c4":
         return bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist)
     map_ids = shard_missions(args.missions_per_gpu, rank, n_ranks)
@@ -554,7 +566,7 @@ def main():
             # the dominant kernel's own rate, from the committed rocprofv3 summary of this very command (a constant tied to the joint
             # solver's sources by hash, like traffic_profiled above; tools/collect_joint_profiles.sh + profiles/README.md say how)
             try:
-                jk = json.load(open(os.path.join(ROOT, "profiles", "r05_joint_kernel.json")))
+                jk = json.load(open(os.path.join(ROOT, "profiles", "r06_joint_kernel.json")))
                 base = os.path.join(ROOT, "swarm_simulator_amd", "csrc", "kernels")
                 h = hashlib.sha256()
                 for f in sorted(os.listdir(base)):
@@ -562,7 +574,7 @@ def main():
                         h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
                 if jk["joint_source_sha"] == h.hexdigest()[:16] and jk["missions_per_gpu"] == K and jk["agents"] == N:
                     out["roofline"]["kernel_profiled"] = {"kernel": jk["kernel"], "achieved": jk["tflops"], "unit": "TFLOP/s",
-                                                          "frac": jk["frac_of_fp64_mfma_peak"], "source": "profiles/r05_joint_kernel.json"}
+                                                          "frac": jk["frac_of_fp64_mfma_peak"], "source": "profiles/r06_joint_kernel.json"}
             except Exception:
                 pass
         # the single-mission latency and the CPU baseline are rank-0, N = 1 legs (the other ranks would only wait for them)
@@ -639,6 +651,48 @@ def dry_run_c4(args, rank, n_ranks, dist):
         oks = [bool(t.item())]
     pairs = sharded.pair_group(dist) is not None if (dist is not None and args.joint) else False
     return {"c4_agent_slices": slices, "c4_gather_ok_on_every_rank": oks[0], "c4_joint_rank_pairs": pairs}
+
+
+def bench_c4_native(args, rank, n_ranks, local_rank, dist):
+    """--config c4 --joint --native-pair: the solve of every rank runs in lib/rbp_c4_joint_rank (csrc/rccl/c4_joint_rank.cpp), a C++ program on
+    the C ABIs alone; with an even number of ranks the pairs {2k, 2k+1} share it through rbp_session_shard_joint_stream +
+    rbp_rccl_exchange_stream (grouped ncclSend / ncclRecv enqueued on the run's stream).  This process only launches it and collects the times."""
+    import subprocess
+    import torch
+    from swarm_simulator_amd import _abi as A
+    exe = os.path.join(A.LIB_DIR, "rbp_c4_joint_rank")
+    if not os.path.exists(exe):
+        raise SystemExit("lib/rbp_c4_joint_rank is not built (needs RCCL headers: __graft_entry__.build())")
+    paired = n_ranks >= 2 and n_ranks % 2 == 0
+    idfile = f"/tmp/rbp_pair_{os.environ.get('MASTER_PORT', '0')}_{rank // 2}_{os.getpid() if not paired else 0}.id"
+    if paired and rank % 2 == 0 and os.path.exists(idfile):
+        os.remove(idfile)
+    if dist is not None:
+        dist.barrier()
+    cmd = [exe, str(rank % 2 if paired else 0), "2" if paired else "1", str(local_rank), idfile, os.path.join(ROOT, "data"), str(args.steps)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=3600)
+    if out.returncode != 0:
+        raise SystemExit(f"rank {rank}: rbp_c4_joint_rank failed ({out.returncode}): {out.stderr[-800:]}")
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    secs = res["ms_per_step"] * 1e-3 * args.steps
+    if dist is not None:
+        t = torch.tensor([secs], dtype=torch.float64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "agent-trajectories/sec (RBP plan: SFC+RSFC+QP)", "value": res["agents"] * args.steps / secs, "unit": "agent-trajectories/s",
+            "n_gpus": n_ranks, "steps": args.steps, "warmup": 1, "ms_per_step": 1e3 * secs / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64",
+            "data": "256-agent mission derived from the reference's 64-agent pattern (tools/make_mission_256.py; no such file upstream), worlds/map1.bt",
+            "config": {"workload": f"ONE {res['agents']}-agent mission (M={res['segments']}) as ONE joint QP (plan/sequential=false), PLANNER stage timed; "
+                                   + ("its knot elimination shared by rank pairs {2k, 2k+1}: " if paired else "whole solve per rank: ") + res["exchange"],
+                       "agents": res["agents"], "segments": res["segments"], "parallelism": "joint factorisation shared by rank pairs" if paired else "replicas",
+                       "process": "lib/rbp_c4_joint_rank (C++ on include/rbp.h, rbp_host.h, rbp_rccl.h; no Python / torch in the solve)",
+                       "qp_iterations": res["qp_iterations"], "qp_unpolished": res["qp_unpolished"], "kkt_max": res["kkt_max"], "baseline_config": "c4",
+                       "all_missions_ok": True}}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def bench_c4(args, param, pkw, rank, n_ranks, local_rank, dist):

@@ -237,6 +237,18 @@ int rbp_session_wait(rbp_session* s);
  * peer.  After RBP_ERR_EXCHANGE on either rank BOTH ranks must give the solve up (undo the sharding, make a new pair). */
 typedef int (*rbp_exchange_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes);
 int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user);
+/* The same with a STREAM-ORDERED exchange (round 6): the hook only ENQUEUES the exchange of `bytes` bytes on `stream` (a hipStream_t: the stream the
+ * run was given) and returns -- ncclSend + ncclRecv in one group on that stream (rbp_rccl_exchange_stream of include/rbp_rccl.h) --, and the library
+ * synchronises for no exchange: it packs, writes the header, calls the hook, and enqueues the kernel that compares the peer's header with its own and
+ * the kernel that unpacks (which does nothing once a header has not matched); the comparison's verdict is read with the once-per-round poll of the
+ * missions' states, and a mismatch ends the run with RBP_ERR_EXCHANGE as above.  ~900 host synchronisations of a 256-agent solve become ~100.
+ * A peer that is gone leaves the stream blocked in its receive: the per-round wait therefore polls with a clock, and after `timeout_s` seconds
+ * (<= 0: for ever) calls `abort_peer(user)` -- may be NULL; rbp_rccl_abort aborts the communicator, which releases both ranks -- and returns
+ * RBP_ERR_EXCHANGE.  Everything else as rbp_session_shard_joint (which it replaces on the session; nranks = 1 undoes either). */
+typedef int (*rbp_exchange_stream_fn)(void* user, void* send_dev, void* recv_dev, size_t bytes, void* stream);
+typedef int (*rbp_exchange_abort_fn)(void* user);
+int rbp_session_shard_joint_stream(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_stream_fn exchange, rbp_exchange_abort_fn abort_peer,
+                                   void* user, double timeout_s);
 /* solver options of this session (default: the context's, else rbp_solver_opts_defaults).  The QP workspace is reserved by the first
  * PLANNER run, for the options then in force: a session that only runs the CORRIDOR stage reserves none. */
 int rbp_session_set_solver_opts(rbp_session* s, const rbp_solver_opts* o);

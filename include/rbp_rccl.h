@@ -24,6 +24,10 @@ typedef struct rbp_rccl_pair rbp_rccl_pair;
 int rbp_rccl_unique_id(void* id_out);
 int rbp_rccl_pair_create(rbp_rccl_pair** out, int device, int rank, int nranks, const void* id);
 int rbp_rccl_exchange(void* pair, void* send_dev, void* recv_dev, size_t bytes);
+/* the same as an rbp_exchange_stream_fn (rbp_session_shard_joint_stream): ncclSend + ncclRecv in one group ENQUEUED on `stream` (a hipStream_t, the
+ * one the run was given); returns at once.  rbp_rccl_abort is the matching rbp_exchange_abort_fn (ncclCommAbort: releases both ranks). */
+int rbp_rccl_exchange_stream(void* pair, void* send_dev, void* recv_dev, size_t bytes, void* stream);
+int rbp_rccl_abort(void* pair);
 /* an exchange that has not completed after `seconds` (default 300; <= 0: wait for ever) aborts the pair's communicator (ncclCommAbort, which
  * also releases a peer blocked in the matching receive) and fails: rbp_session_run returns RBP_ERR_EXCHANGE on both ranks.  The same
  * happens on any RCCL / HIP error of an exchange; a pair that has failed once stays failed (create a new one). */

@@ -627,27 +627,36 @@ int rbp_session_wait(rbp_session* s) {
     return join_worker(s);
 }
 
-int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user) {
+static int shard_joint_impl(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, rbp_exchange_stream_fn exchange_stream,
+                            rbp_exchange_abort_fn abort_peer, void* user, double timeout_s) {
     if (!s) return fail(RBP_ERR_BAD_ARGUMENT, "null session");
     if (int jrc = join_worker(s)) return jrc;
     if (nranks == 1) {  // undo: this session runs both chains again (the buffers stay until destroy)
-        s->shard.nranks = 1, s->shard.rank = 0, s->shard.exchange = nullptr, s->shard.user = nullptr;
+        s->shard.nranks = 1, s->shard.rank = 0, s->shard.exchange = nullptr, s->shard.exchange_stream = nullptr, s->shard.abort_peer = nullptr, s->shard.user = nullptr;
         return RBP_OK;
     }
-    if (nranks != 2 || rank < 0 || rank > 1 || !exchange)
+    if (nranks != 2 || rank < 0 || rank > 1 || (!exchange && !exchange_stream))
         return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: the twisted elimination has two chains -- nranks must be 2 (or 1 to undo), rank 0 or 1, and an exchange hook is needed");
     if (s->param.sequential || s->d.N < 2)
         return fail(RBP_ERR_BAD_ARGUMENT, "rbp_session_shard_joint: only a joint QP (plan/sequential = false) has a factorisation to share; the sequential schedule shards by mission");
     const size_t cap = joint_exchange_bytes(s->d.N, s->d.M, s->d.K);
     if (!s->shard_buf) {
         HIP_TRY(hipSetDevice(s->device));
-        const hipError_t e = hipMalloc((void**)&s->shard_buf, 2 * cap);
+        const hipError_t e = hipMalloc((void**)&s->shard_buf, 2 * cap + 64);  // (+ the error word of the stream-ordered exchange)
         if (e != hipSuccess)
             return fail(RBP_ERR_HIP, "rbp_session_shard_joint: exchange buffers (2 x " + std::to_string(cap) + " bytes) could not be reserved: " + hipGetErrorString(e));
     }
     s->shard.rank = rank, s->shard.nranks = 2, s->shard.send = (double*)s->shard_buf, s->shard.recv = (double*)(s->shard_buf + cap), s->shard.cap = cap;
-    s->shard.exchange = exchange, s->shard.user = user;
+    s->shard.xerr = (double*)(s->shard_buf + 2 * cap);
+    s->shard.exchange = exchange, s->shard.exchange_stream = exchange_stream, s->shard.abort_peer = abort_peer, s->shard.user = user, s->shard.timeout_s = timeout_s;
     return RBP_OK;
+}
+int rbp_session_shard_joint(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_fn exchange, void* user) {
+    return shard_joint_impl(s, rank, nranks, exchange, nullptr, nullptr, user, 0.0);
+}
+int rbp_session_shard_joint_stream(rbp_session* s, int32_t rank, int32_t nranks, rbp_exchange_stream_fn exchange, rbp_exchange_abort_fn abort_peer, void* user,
+                                   double timeout_s) {
+    return shard_joint_impl(s, rank, nranks, nullptr, exchange, abort_peer, user, timeout_s);
 }
 
 int rbp_session_download(rbp_session* s, rbp_plan* plans, int32_t* status, void* stream) {

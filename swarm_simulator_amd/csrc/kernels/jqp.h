@@ -54,6 +54,13 @@ struct JointShard {
     double *send = nullptr, *recv = nullptr;  // device buffers of `cap` bytes each (the session's)
     size_t cap = 0;
     int (*exchange)(void* user, void* send_dev, void* recv_dev, size_t bytes) = nullptr;  // returns 0 when the peer's bytes are in recv
+    // STREAM-ORDERED form (rbp_session_shard_joint_stream): only ENQUEUES the exchange on `stream` and returns; the library then neither
+    // synchronises before nor after a call -- the header of every exchange is written and checked by kernels, a mismatch lands in *xerr
+    // (device) and is read with the once-per-round poll of the missions' states
+    int (*exchange_stream)(void* user, void* send_dev, void* recv_dev, size_t bytes, void* stream) = nullptr;
+    int (*abort_peer)(void* user) = nullptr;  // optional: brings the exchange down (ncclCommAbort) when the per-round wait times out
+    double timeout_s = 300.0;                 // of one round's wait (stream-ordered form)
+    double* xerr = nullptr;                   // [2] device: {which header word differed (1..6; 0 = none), sequence number of that exchange}
     void* user = nullptr;
 };
 size_t joint_exchange_bytes(int N, int MS, int K);  // capacity the send / recv buffers of a K-mission session need

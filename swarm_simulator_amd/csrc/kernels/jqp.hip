@@ -35,8 +35,10 @@
 // Layout: knot matrices are TILE-MAJOR (64 x 64 tiles of 32 KB, row-major inside), order nkp = nk rounded up to 64 (identity
 // padding).  During the sweep only tiles I >= J are valid; the last step writes S_j^-1 with both triangles.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "jqp.h"
@@ -1783,9 +1785,27 @@ __global__ __launch_bounds__(256) void jq_mv(JArgs A, int mode, int s) {
 // a hang or silently wrong data.  Slot 5 is the poison word: a rank that fails locally sends it so that its peer stops too.
 #define JQ_XHDR 8
 #define JQ_XMAGIC 1380077656.0 /* "RBPX" */
-__global__ __launch_bounds__(256) void jq_xfer(JArgs A, int what, int dir, int chain, double* buf) {
+// the same header for the stream-ordered exchange (JointShard::exchange_stream): written into the send buffer and compared with the peer's
+// in the receive buffer BY KERNELS, in stream order -- no host synchronisation per exchange.  A mismatch is recorded in xerr (first one
+// wins) and every later unpack of the run is skipped (jq_xfer reads xerr); the host finds it at the next per-round poll.
+__global__ void jq_xhdr_write(double* send, double seq, double what, double bytes, double hash) {
+    if (threadIdx.x == 0)
+        send[0] = JQ_XMAGIC, send[1] = seq, send[2] = what, send[3] = bytes, send[4] = hash, send[5] = 0.0, send[6] = 0.0, send[7] = 0.0;
+}
+__global__ void jq_xhdr_check(const double* recv, double seq, double what, double bytes, double hash, double* xerr) {
+    if (threadIdx.x != 0 || xerr[0] != 0.0) return;
+    const double mine[6] = {JQ_XMAGIC, seq, what, bytes, hash, 0.0};
+    const int order[6] = {0, 5, 1, 2, 3, 4};
+    for (int oi = 0; oi < 6; ++oi)
+        if (recv[order[oi]] != mine[order[oi]]) {
+            xerr[0] = (double)(order[oi] + 1), xerr[1] = seq;
+            return;
+        }
+}
+__global__ __launch_bounds__(256) void jq_xfer(JArgs A, int what, int dir, int chain, double* buf, const double* xerr) {
     const DevSession& S = A.S;
     const int mission = blockIdx.y;
+    if (dir == 1 && xerr && xerr[0] != 0.0) return;  // (stream-ordered exchange: the header did not match -- what lies in buf is not ours to unpack)
     const Ws w = carve(A, mission);
     if (w.st[ST_STATE] != 0.0 || w.st[ST_RETRY] != 0.0 || w.st[ST_GO] != 0.0) return;
     if (what != 0) {
@@ -2013,8 +2033,10 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             if (p) (void)hipHostFree(p);
         }
     } pinned;
-    if (hipHostMalloc((void**)&pinned.p, sizeof(double) * K * ST_N) != hipSuccess) return RBP_ERR_HIP;
+    if (hipHostMalloc((void**)&pinned.p, sizeof(double) * ((size_t)K * ST_N + 2)) != hipSuccess) return RBP_ERR_HIP;
     double* state_h = pinned.p;
+    double* xerr_h = pinned.p + (size_t)K * ST_N;  // (stream-ordered pair: JointShard::xerr as of the last poll)
+    xerr_h[0] = xerr_h[1] = 0.0;
     // jq_mv keeps one vector of nkp doubles in dynamic LDS: above the default 64 KB the limit has to be raised, above the CU's 160 KB
     // (N > 2275 agents) the launch cannot be made at all
     if ((size_t)dm.nkp * sizeof(double) > 160 * 1024) return RBP_ERR_BAD_ARGUMENT;
@@ -2024,7 +2046,35 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
     const JointShard* sh = opts.shard && opts.shard->nranks == 2 ? opts.shard : nullptr;
     const int ychains = sh ? 1 : 2, my_chain = sh ? sh->rank : 0;
     int xrc = RBP_OK;
-    if (sh && (!sh->exchange || !sh->send || !sh->recv || sh->cap < joint_exchange_bytes(N, s.M, K) || sh->rank < 0 || sh->rank > 1)) return RBP_ERR_BAD_ARGUMENT;
+    if (sh && ((!sh->exchange && !sh->exchange_stream) || !sh->send || !sh->recv || sh->cap < joint_exchange_bytes(N, s.M, K) || sh->rank < 0 || sh->rank > 1 ||
+               (sh->exchange_stream && !sh->xerr)))
+        return RBP_ERR_BAD_ARGUMENT;
+    if (sh && sh->exchange_stream && hipMemsetAsync(sh->xerr, 0, 2 * sizeof(double), st) != hipSuccess) return RBP_ERR_HIP;
+    // the per-round wait of a stream-ordered pair: a peer that is gone leaves the stream blocked in its receive for ever, so the wait polls
+    // with a clock; on time-out the hook's owner is asked to bring the exchange down (abort_peer) and the run ends with RBP_ERR_EXCHANGE
+    auto wait_round = [&]() -> int {
+        if (!(sh && sh->exchange_stream)) return hipStreamSynchronize(st) == hipSuccess ? RBP_OK : RBP_ERR_HIP;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return RBP_OK;
+            if (q != hipErrorNotReady) return RBP_ERR_HIP;
+            if (sh->timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sh->timeout_s) {
+                if (sh->abort_peer) (void)sh->abort_peer(sh->user);
+                return rbp_set_error(RBP_ERR_EXCHANGE, "joint QP: timed out waiting for a round of the stream-ordered exchange (the peer rank is gone or stuck); both ranks must abort");
+            }
+            if (spin > 4000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    };
+    auto xerr_check = [&](const double* xe) -> int {  // xe: host copy of sh->xerr taken with the poll
+        if (xe[0] == 0.0) return RBP_OK;
+        static const char* const names[6] = {"magic", "sequence number", "kind", "byte count", "state hash", "poison word (the peer rank failed)"};
+        char msg[320];
+        const int f = (int)xe[0] - 1;
+        snprintf(msg, sizeof(msg), "joint QP: exchange %.0f does not match the peer rank's: %s differs -- the two ranks of the pair have diverged or one has failed; "
+                 "both must abort", xe[1], names[f >= 0 && f < 6 ? f : 0]);
+        return rbp_set_error(RBP_ERR_EXCHANGE, msg);
+    };
     double xseq = 0;
     auto state_hash = [&]() {  // FNV-1a over the state words polled last and the host variables the launch pattern depends on
         unsigned long long h = 1469598103934665603ull;
@@ -2054,7 +2104,19 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         const size_t bytes = (JQ_XHDR + (size_t)K * slot) * sizeof(double);
         const dim3 grid((unsigned)std::min<size_t>((slot + 255) / 256, 2048), K);
         const double mine[JQ_XHDR] = {JQ_XMAGIC, xseq, (double)what, (double)bytes, state_hash(), 0.0, 0.0, 0.0};
-        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send + JQ_XHDR);
+        if (sh->exchange_stream) {  // stream-ordered: pack, header, exchange, check, unpack -- all enqueued, nothing waited for
+            JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send + JQ_XHDR, (const double*)nullptr);
+            hipLaunchKernelGGL(jq_xhdr_write, dim3(1), dim3(64), 0, st, sh->send, mine[1], mine[2], mine[3], mine[4]);
+            if (sh->exchange_stream(sh->user, sh->send, sh->recv, bytes, (void*)st) != 0) {
+                xrc = rbp_set_error(RBP_ERR_EXCHANGE, "joint QP: the stream-ordered exchange hook of rbp_session_shard_joint_stream reported a failure");
+                return;
+            }
+            hipLaunchKernelGGL(jq_xhdr_check, dim3(1), dim3(64), 0, st, sh->recv, mine[1], mine[2], mine[3], mine[4], sh->xerr);
+            JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv + JQ_XHDR, (const double*)sh->xerr);
+            xseq += 1;
+            return;
+        }
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 0, my_chain, sh->send + JQ_XHDR, (const double*)nullptr);
         if (hipMemcpyAsync(sh->send, mine, sizeof(mine), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             xrc = RBP_ERR_HIP;
             poison_peer(what);
@@ -2082,7 +2144,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
             return;
         }
         xseq += 1;
-        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv + JQ_XHDR);
+        JQ_LAUNCH(jq_xfer, grid, 0, A, what, 1, 1 - my_chain, sh->recv + JQ_XHDR, (const double*)nullptr);
     };
     auto substitute = [&](int which_out) {
         A.chain0 = my_chain;
@@ -2186,7 +2248,7 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
                                 hipMemcpyDeviceToHost, st) == hipSuccess &&
                hipMemcpy2DAsync(cnt_h.data(), sizeof(int) * PC_N, A.ws + L.o_pol + PL.cnt, L.stride * sizeof(double), sizeof(int) * PC_N, K,
                                 hipMemcpyDeviceToHost, st) == hipSuccess &&
-               hipStreamSynchronize(st) == hipSuccess;
+               wait_round() == RBP_OK;
     };
     auto polish = [&]() -> int {
         for (int k = 0; k < K; ++k)
@@ -2269,10 +2331,12 @@ int launch_planner_joint(const DevSession& s, void* ws, hipStream_t st, JointSta
         // is any mission still running?  (one synchronisation per iteration)
         if (hipMemcpy2DAsync(state_h, sizeof(double) * ST_N, A.ws + L.o_state, L.stride * sizeof(double), sizeof(double) * ST_N, K,
                              hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {
+            (sh && sh->exchange_stream && hipMemcpyAsync(xerr_h, sh->xerr, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)) {
             rc = RBP_ERR_HIP;
             break;
         }
+        if ((rc = wait_round()) != RBP_OK) break;
+        if ((rc = xerr_check(xerr_h)) != RBP_OK) break;  // (a stream-ordered exchange of the last round did not match the peer's)
         bool running = false;
         for (int k = 0; k < K; ++k) running = running || state_h[(size_t)k * ST_N + ST_STATE] == 0.0;
         if (trace)

@@ -100,6 +100,29 @@ int rbp_rccl_exchange(void* pair, void* send_dev, void* recv_dev, size_t bytes) 
     }
 }
 
+// the stream-ordered form (rbp_exchange_stream_fn): the grouped send / receive is enqueued on the CALLER's stream and the call returns
+int rbp_rccl_exchange_stream(void* pair, void* send_dev, void* recv_dev, size_t bytes, void* stream) {
+    rbp_rccl_pair* p = static_cast<rbp_rccl_pair*>(pair);
+    if (!p || !send_dev || !recv_dev) return fail("rbp_rccl_exchange_stream: null argument");
+    if (p->aborted || !p->comm) return fail("rbp_rccl_exchange_stream: the pair's communicator was aborted by an earlier failure");
+    if (bytes == 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ncclResult_t r = ncclGroupStart();
+    if (r == ncclSuccess) r = ncclSend(send_dev, bytes, ncclChar, p->peer, p->comm, st);
+    if (r == ncclSuccess) r = ncclRecv(recv_dev, bytes, ncclChar, p->peer, p->comm, st);
+    const ncclResult_t e = ncclGroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) return abort_pair(p, std::string("rbp_rccl_exchange_stream: ") + ncclGetErrorString(r));
+    return 0;
+}
+// rbp_exchange_abort_fn: what rbp_session_shard_joint_stream calls when a round of the exchange has timed out
+int rbp_rccl_abort(void* pair) {
+    rbp_rccl_pair* p = static_cast<rbp_rccl_pair*>(pair);
+    if (!p) return fail("rbp_rccl_abort: null pair");
+    (void)abort_pair(p, "rbp_rccl_abort: aborted on request");
+    return 0;
+}
+
 int rbp_rccl_pair_set_timeout(rbp_rccl_pair* p, double seconds) {
     if (!p) return fail("rbp_rccl_pair_set_timeout: null pair");
     p->timeout_s = seconds;

@@ -38,6 +38,22 @@ int main() {
         std::printf("exchange of %zu bytes: %llu words differ\n", n * 8, h);
         if (h) return 8;
     }
+    // the stream-ordered form (rbp_exchange_stream_fn): fill, exchange and comparison are ENQUEUED on one stream, nothing waits in between
+    {
+        hipStream_t st;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 9;
+        const size_t n = sizes[1];
+        (void)hipMemsetAsync(recv, 0xFF, n * 8, st);
+        (void)hipMemsetAsync(cnt, 0, 8, st);
+        hipLaunchKernelGGL(fill, dim3(256), dim3(256), 0, st, send, n, 7.0);
+        if (rbp_rccl_exchange_stream(pair, send, recv, n * 8, (void*)st)) return std::printf("exchange_stream: %s\n", rbp_rccl_last_error()), 10;
+        hipLaunchKernelGGL(differ, dim3(256), dim3(256), 0, st, send, recv, n, cnt);
+        unsigned long long h = 1;
+        if (hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 11;
+        std::printf("stream-ordered exchange of %zu bytes: %llu words differ\n", n * 8, h);
+        if (h) return 12;
+        (void)hipStreamDestroy(st);
+    }
     rbp_rccl_pair_destroy(pair);
     std::printf("rbp_rccl selftest ok\n");
     return 0;

@@ -31,6 +31,8 @@ ERROR_TEXT = {
 
 # rbp_exchange_fn of include/rbp.h: int (*)(void* user, void* send_dev, void* recv_dev, size_t bytes)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+EXCHANGE_STREAM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)   # rbp_exchange_stream_fn (+ the stream)
+EXCHANGE_ABORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)                                                    # rbp_exchange_abort_fn
 
 
 class RbpLibraryMissing(RuntimeError):
@@ -100,6 +102,7 @@ def lib():
         L.rbp_session_run_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rbp_session_wait.argtypes = [C.c_void_p]
         L.rbp_session_shard_joint.argtypes = [C.c_void_p, C.c_int32, C.c_int32, EXCHANGE_FN, C.c_void_p]
+        L.rbp_session_shard_joint_stream.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         L.rbp_session_download.argtypes = [C.c_void_p, P(A.rbp_plan), A.c_int32_p, C.c_void_p]
         L.rbp_session_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.rbp_session_counters.argtypes = [C.c_void_p, P(A.rbp_counters), C.c_void_p]
@@ -133,7 +136,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rbp_param_defaults", "rbp_corridor_update", "rbp_corridor_update_range", "rbp_planner_update", "rbp_session_create",
-    "rbp_session_run", "rbp_session_run_async", "rbp_session_wait", "rbp_session_shard_joint", "rbp_session_set_agent_range",
+    "rbp_session_run", "rbp_session_run_async", "rbp_session_wait", "rbp_session_shard_joint", "rbp_session_shard_joint_stream", "rbp_session_set_agent_range",
     "rbp_session_download", "rbp_session_reset", "rbp_session_destroy", "rbp_session_counters", "rbp_session_scalars",
     "rbp_session_device_arrays",
     "rbp_version", "rbp_abi_version", "rbp_sizeof", "rbp_release_thread_context",

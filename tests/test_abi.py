@@ -162,7 +162,7 @@ def test_rccl_library_exports_every_symbol_of_rbp_rccl_h():
     hdr = open(os.path.join(root, "include", "rbp_rccl.h")).read()
     declared = set(re.findall(r"\b(rbp_rccl_[a-z_]+)\s*\(", hdr.split("#ifdef __cplusplus")[1]))
     assert declared == {"rbp_rccl_unique_id", "rbp_rccl_pair_create", "rbp_rccl_exchange", "rbp_rccl_pair_destroy", "rbp_rccl_last_error",
-                        "rbp_rccl_pair_set_timeout"}
+                        "rbp_rccl_pair_set_timeout", "rbp_rccl_exchange_stream", "rbp_rccl_abort"}
     nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
     syms = subprocess.run([nm, "-D", "--defined-only", so], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (rbp_rccl_[a-z_]+)", syms))

@@ -80,6 +80,114 @@ class _Pair:
         return hook
 
 
+class _StreamPair:
+    """the STREAM-ORDERED exchange (rbp_session_shard_joint_stream) between two sessions of one process, each on a stream of its own: a hook
+    only enqueues -- it waits (on its stream, by an event) for the peer's pack, copies device to device on its stream, and makes its
+    stream wait for the peer's copy before the library may pack again.  The two host threads meet at a barrier to trade pointers and events;
+    nothing synchronises a stream with the host."""
+
+    def __init__(self, corrupt=None):
+        import torch
+        self.torch = torch
+        self.corrupt = corrupt
+        self.barrier = threading.Barrier(2, timeout=120)
+        self.posted, self.copied = [None, None], [None, None]
+        self.calls, self.bytes = [0, 0], [0, 0]
+        self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        self.hooks = [planner.EXCHANGE_STREAM_FN(self._make(r)) for r in range(2)]
+
+    def _make(self, rank):
+        torch = self.torch
+
+        class _View:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+        def hook(user, send_ptr, recv_ptr, nbytes, stream_ptr):
+            try:
+                st = torch.cuda.ExternalStream(int(stream_ptr))
+                ev = torch.cuda.Event()
+                ev.record(st)                       # (the library's pack and header kernels are in front of it)
+                self.posted[rank] = (send_ptr, nbytes, ev)
+                self.barrier.wait()
+                peer_ptr, peer_bytes, peer_ev = self.posted[1 - rank]
+                if peer_bytes != nbytes:
+                    return 2
+                st.wait_event(peer_ev)
+                n = nbytes // 8
+                with torch.cuda.stream(st):
+                    dst = torch.as_tensor(_View(recv_ptr, n), device="cuda")
+                    dst.copy_(torch.as_tensor(_View(peer_ptr, n), device="cuda"), non_blocking=True)
+                    if self.corrupt and self.corrupt[0] == rank and self.corrupt[1] == self.calls[rank]:
+                        dst[self.corrupt[2]] += 1.0
+                done = torch.cuda.Event()
+                done.record(st)
+                self.copied[rank] = done
+                self.barrier.wait()
+                st.wait_event(self.copied[1 - rank])   # the peer has read my send buffer before the library packs the next exchange into it
+                self.calls[rank] += 1
+                self.bytes[rank] += nbytes
+                return 0
+            except BaseException:
+                return 1
+        return hook
+
+
+def test_stream_ordered_exchange_gives_the_bits_of_the_unsharded_solve():
+    """rbp_session_shard_joint_stream: pack, header, exchange, header check and unpack are all enqueued on the run's stream -- the library
+    synchronises once per interior-point round, not per exchange -- and both ranks still end with the bits of the one-GPU solve"""
+    p, m, worlds, inits = _inputs(32, [7])
+    alone = _run_alone(p, m, worlds, inits)
+    pair = _StreamPair()
+    plans = [[i.clone() for i in inits] for _ in range(2)]
+    sessions = [planner.Session(worlds, [m], p, plans[r]) for r in range(2)]
+    L = planner.lib()
+    for r, s in enumerate(sessions):
+        assert L.rbp_session_shard_joint_stream(s._h, r, 2, C.cast(pair.hooks[r], C.c_void_p), None, None, 120.0) == 0, planner.last_error()
+    errs = [None, None]
+
+    def work(r):
+        try:
+            sessions[r].run(A.RBP_STAGE_PLANNER, stream=pair.streams[r].cuda_stream)
+        except BaseException as e:
+            errs[r] = e
+            pair.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=PAIR_TIMEOUT_S) for t in th]
+    assert not any(t.is_alive() for t in th), f"a rank hung (exchanges so far: {pair.calls})"
+    assert errs == [None, None], errs
+    sts = [s.download(pair.streams[r].cuda_stream) for r, s in enumerate(sessions)]
+    [s.close() for s in sessions]
+    assert sts == [[0], [0]]
+    assert _same_bits(plans[0][0], alone[0]) and _same_bits(plans[1][0], alone[0])
+    assert pair.calls[0] == pair.calls[1] > 3 * alone[0].qp_iterations
+
+
+def test_stream_ordered_exchange_catches_a_header_that_does_not_match():
+    """the header comparison of the stream-ordered exchange runs on the device; its verdict comes back with the next per-round poll"""
+    p, m, worlds, inits = _inputs(16, [3])
+    pair = _StreamPair(corrupt=(1, 5, 1))   # rank 1's sixth exchange arrives with another sequence number
+    sessions = [planner.Session(worlds, [m], p, [inits[0].clone()]) for _ in range(2)]
+    L = planner.lib()
+    for r, s in enumerate(sessions):
+        assert L.rbp_session_shard_joint_stream(s._h, r, 2, C.cast(pair.hooks[r], C.c_void_p), None, None, 30.0) == 0
+    out = [None, None]
+
+    def work(r):
+        rc = L.rbp_session_run(sessions[r]._h, A.RBP_STAGE_PLANNER, C.c_void_p(pair.streams[r].cuda_stream))
+        out[r] = (rc, planner.last_error())
+        if rc:
+            pair.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=PAIR_TIMEOUT_S) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank hung"
+    assert out[1][0] == A.RBP_ERR_EXCHANGE and "sequence number" in out[1][1] and "diverged" in out[1][1], out
+    assert out[0][0] == A.RBP_ERR_EXCHANGE, out     # its peer is gone: the hook fails (or its own round times out)
+    [s.close() for s in sessions]
+
+
 def _run_pair(p, m, worlds, inits, **opts):
     """the same missions in two sessions sharing every joint solve; returns (plans of rank 0, plans of rank 1, pair)"""
     pair = _Pair()

@@ -2,7 +2,9 @@
 `bench.py --joint --agents 64 --missions-per-gpu 200 --steps 1 --warmup 1` (two steps in the trace) and the flops the solver logs per step
 (the bench line of the same workload), tied to the joint solver's sources by hash (bench.py prints it only while the hash matches).
 
-usage: python tools/joint_kernel_json.py <joint_kernel_stats.csv> <joint_bench_200.log> <out.json> [nblk nj]"""
+usage: python tools/joint_kernel_json.py <joint_kernel_stats.csv> <joint_bench_200.log> <out.json> [joint_pmc.txt] [nblk nj]
+(joint_pmc.txt: the per-kernel FETCH_SIZE / WRITE_SIZE sums tools/collect_round.sh writes; gives hbm_bytes_per_launch of the update kernel with the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md: the counters are in KB, FETCH_SIZE counts half of the bytes of wide reads)"""
 import csv
 import hashlib
 import json
@@ -11,7 +13,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stats, benchlog, out = sys.argv[1:4]
-nblk, nj = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (9, 35)
+rest = sys.argv[4:]
+pmc_txt = rest.pop(0) if rest and not rest[0].isdigit() else None
+nblk, nj = (int(rest[0]), int(rest[1])) if len(rest) > 1 else (9, 35)
 rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
 # the update kernel of the schedule in force: jq_update (look-ahead, the automatic choice since round 5's lean kernel) or jq_update_bulk
 cands = [(float(r["TotalDurationNs"]), ("jq_update_bulk" if "jq_update_bulk" in n else "jq_update"), r) for n, r in rows.items()
@@ -33,7 +37,21 @@ for f in sorted(os.listdir(base)):
     if f.startswith("jqp"):
         h.update(f.encode()), h.update(open(os.path.join(base, f), "rb").read())
 tflops = share * flops * 2 / secs / 1e12
-json.dump({"joint_source_sha": h.hexdigest()[:16], "missions_per_gpu": b["config"]["missions_per_gpu"], "agents": b["config"]["agents"],
+traffic = None
+if pmc_txt and os.path.exists(pmc_txt):
+    import re
+    txt = open(pmc_txt).read()
+    # blocks "kernel\n   COUNTER total X over N dispatches -> Y per dispatch"; the HBM part follows the "---- HBM side" line
+    hbm = txt.split("---- HBM side")[-1]
+    def per_dispatch(counter):
+        mm = re.search(r"^" + re.escape(kname) + r"\n(?:   .*\n)*?   " + counter + r"\s+total\s+\S+ over \d+ dispatches -> (\S+) per dispatch", hbm, re.M)
+        return float(mm.group(1)) if mm else None
+    fe, wr = per_dispatch("FETCH_SIZE"), per_dispatch("WRITE_SIZE")
+    if fe is not None and wr is not None:
+        traffic = {"fetch_bytes_per_launch": 2.0 * fe * 1024.0, "write_bytes_per_launch": wr * 1024.0,
+                   "hbm_bytes_per_launch": 2.0 * fe * 1024.0 + wr * 1024.0,
+                   "correction": "FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of the bytes of wide reads (x2)"}
+json.dump({"traffic": traffic,"joint_source_sha": h.hexdigest()[:16], "missions_per_gpu": b["config"]["missions_per_gpu"], "agents": b["config"]["agents"],
            "kernel": kname, "launches": int(k["Calls"]), "kernel_seconds_two_steps": secs, "logged_flops_per_step": flops,
            "share_of_logged_flops_in_this_kernel": share,
            "share_derivation": f"tile counts of jq_count (kernels/jqp.hip): update tiles (nblk-1) nblk / 2 against panel tiles (nblk-1) per 64-column step, "
