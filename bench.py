@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--joint", action="store_true", help="plan/sequential=false: one QP over all agents of a mission")
     ap.add_argument("--qp-schedule", choices=["auto", "mono", "phase"], default="auto",
                     help="rbp_solver_opts.qp_schedule: one workgroup per mission runs a mission's whole schedule (mono = the default) / the "
-                         "phase-split schedule with chip-wide row sweeps (kernels/qp_phase.inc); A/B runs")
+                         "phase-split schedule with chip-wide row sweeps (kernels/qp_phase.inc: developer build only, RBP_HIP_LIB=.../librbp_hip_dev.so); A/B runs")
     ap.add_argument("--qp-groups", type=int, default=0, help="rbp_solver_opts.qp_groups (phase split: streams)")
     ap.add_argument("--qp-variant", choices=["auto", "w2", "w4"], default="auto", help="rbp_solver_opts.qp_variant (A/B runs)")
     ap.add_argument("--qp-far-slack", type=float, default=None, help="rbp_solver_opts.qp_far_slack [m] (A/B runs; default: the library's 0.7)")

@@ -591,6 +591,9 @@ static int run_impl(rbp_session* s, int stages, void* stream, bool async) {
         if (rc == RBP_ERR_EXCHANGE) return rc;  // (kernels/jqp.hip has recorded which exchange failed and why)
         if (rc) return fail(rc, "joint QP: HIP error");
         launch_planner_epilogue(s->d, st);
+    } else if ((stages & RBP_STAGE_PLANNER) && o.qp_schedule == 2 && !planner_has_phase_split()) {
+        return fail(RBP_ERR_BAD_ARGUMENT, "rbp_solver_opts.qp_schedule = 2: the phase-split schedule is not part of the release library (it loses everywhere: DESIGN.md 3.3); "
+                                          "the developer build lib/librbp_hip_dev.so (`make dev`) carries it");
     } else if ((stages & RBP_STAGE_PLANNER) && o.qp_schedule == 2) {
         // phase split (kernels/qp_phase.inc): chip-wide row sweeps, one workgroup per mission for the chains; the missions are spread over a
         // few streams whose rounds overlap

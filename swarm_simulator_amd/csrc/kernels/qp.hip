@@ -3008,7 +3008,9 @@ __global__ __launch_bounds__(256) void qp_order_kernel(DevSession S) {
         S.qp_order[k] = k;
 }
 
-#if QP_THREADS == 256
+// the phase-split schedule (round 5: built, measured, loses everywhere -- DESIGN.md 3.3) is NOT part of the release library: `make dev`
+// (-DRBP_PHASE_SPLIT) compiles it into lib/librbp_hip_dev.so, where rbp_solver_opts.qp_schedule = 2 selects it (tests/test_gpu_phase.py)
+#if QP_THREADS == 256 && defined(RBP_PHASE_SPLIT)
 #include "qp_phase.inc"
 #endif
 
@@ -3494,7 +3496,12 @@ void QP_CAT(launch_planner, QP_SUFFIX)(const DevSession& s, void* qp_ws, size_t 
     hipLaunchKernelGGL(timescale_kernel, dim3(s.K), dim3(256), 0, st, s);
 }
 
-#if QP_THREADS == 256
+#if QP_THREADS == 256 && !defined(RBP_PHASE_SPLIT)
+void launch_planner_phased(const DevSession&, void*, size_t, hipStream_t, hipStream_t*, hipEvent_t*, int, int) {}  // (never reached: abi/session.hip refuses qp_schedule = 2)
+bool planner_has_phase_split() { return false; }
+#endif
+#if QP_THREADS == 256 && defined(RBP_PHASE_SPLIT)
+bool planner_has_phase_split() { return true; }
 // The PHASE-SPLIT schedule (kernels/qp_phase.inc): a fixed budget of rounds is enqueued on G streams (one group of missions each, forked
 // from and joined back into the caller's stream by events), nothing is synchronised.  rounds <= 0: the default budget of
 // QP_ROUNDS_PER_QP rounds per batch QP of the schedule (a batch QP takes ~18 interior-point iterations = rounds).

@@ -97,5 +97,6 @@ void launch_planner_w4(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_
 // the phase-split schedule of the batch QPs (kernels/qp_phase.inc; exported by the 256-thread build): gs[G] group streams, gev[1 + G] events
 void launch_planner_phased(const DevSession& s, void* qp_ws, size_t qp_ws_bytes_per_mission, hipStream_t st, hipStream_t* gs, hipEvent_t* gev, int G,
                            int rounds);
+bool planner_has_phase_split();  // false in the release library (kernels/qp_phase.inc is compiled by `make dev` only)
 size_t planner_workspace_bytes_w2(int N, int M, int batch_size_eff);
 size_t planner_workspace_bytes_w4(int N, int M, int batch_size_eff);

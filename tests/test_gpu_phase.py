@@ -1,4 +1,5 @@
-"""The PHASE-SPLIT schedule of the batch QPs (kernels/qp_phase.inc, rbp_solver_opts.qp_schedule = 2): chip-wide row sweeps as kernels of
+"""The PHASE-SPLIT schedule of the batch QPs (kernels/qp_phase.inc, rbp_solver_opts.qp_schedule = 2; since round 6 in the developer build
+lib/librbp_hip_dev.so only -- the release library refuses it -- so its cases, tests/phase_split_cases.py, run in a process of their own): chip-wide row sweeps as kernels of
 their own, one workgroup per mission for chains and polish, a fixed budget of rounds enqueued without synchronisation.  Same device
 functions as qp_batch_kernel (one workgroup per mission for everything, the default); only the block reductions of a sweep are summed in a
 different order (and the monolith's interior-point phase works on the reduced row set of QP_FAR_SLACK in the first pass, the phase split on
@@ -27,38 +28,30 @@ def _run(worlds, missions, p, inits, times=1, **opts):
     return plans, outs
 
 
-@pytest.mark.parametrize("agents,batch,iteration,maps", [(64, 4, 1, [1, 2, 46, 4, 5, 6]), (16, 8, 3, [3, 9]), (8, 3, 1, [5])])
-def test_phase_split_equals_one_workgroup_per_mission(agents, batch, iteration, maps):
-    """ragged session (M = 34..37), a last batch shorter than the others (8 agents in batches of 3), several Gauss-Seidel passes with the
-    polish-first shortcut, the tiled path (batches of 8): the two schedules agree to 2e-7 m, solve and polish the same QPs; two groups of
-    missions on two streams give the same bits as one"""
-    p = Param.test_sweep(batch_size=batch, iteration=iteration)
-    m = host.load_mission(f"mission_{agents}agents_15.json")
-    worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
-    inits = [host.ecbs_plan(w, m, p) for w in worlds]
-    mono, _ = _run(worlds, [m] * len(maps), p, inits, qp_schedule=1)
-    phase, (r1, r2) = _run(worlds, [m] * len(maps), p, inits, times=2, qp_schedule=2, qp_groups=1)
-    _, (g2,) = _run(worlds, [m] * len(maps), p, inits, qp_schedule=2, qp_groups=2)
-    for a, b in zip(mono, phase):
-        assert b.qp_solves == a.qp_solves and b.qp_unpolished == 0 and a.qp_unpolished == 0
-        assert np.abs(a.ctrl - b.ctrl).max() < 2e-7
-        assert abs(a.total_cost - b.total_cost) <= 1e-8 * max(1.0, abs(a.total_cost))
-        obj, veq, vbox, vrs = O.evaluate_ctrl(m, b)
-        assert veq < 5e-8 and vbox < 1e-8 and vrs < 1e-8
-    for x, y, z in zip(r1, r2, g2):
-        assert np.array_equal(x.view(np.uint64), y.view(np.uint64)) and np.array_equal(x.view(np.uint64), z.view(np.uint64))
-
-
-def test_phase_split_round_budget_fails_loudly():
-    """a mission the round budget does not finish is an error (RBP_ERR_QP_FAILED), never a half-solved plan"""
+def test_release_library_refuses_the_phase_split_schedule():
+    """kernels/qp_phase.inc lost every comparison and is compiled by `make dev` only: the release library says so, before any launch"""
     p = Param.test_sweep()
     m = host.load_mission("mission_8agents_15.json")
     w = host.load_world("map5.bt", p)
     g = host.ecbs_plan(w, m, p)
-    sess = planner.Session([w], [m], p, [g], opts=planner.solver_opts(qp_schedule=2, qp_rounds=5))
-    sess.run(A.RBP_STAGE_ALL)
-    assert sess.download() == [A.RBP_ERR_QP_FAILED]
+    sess = planner.Session([w], [m], p, [g], opts=planner.solver_opts(qp_schedule=2))
+    with pytest.raises(RuntimeError, match="phase-split schedule is not part of the release library"):
+        sess.run(A.RBP_STAGE_ALL)
     sess.close()
+
+
+def test_phase_split_cases_in_the_developer_build():
+    """tests/phase_split_cases.py against lib/librbp_hip_dev.so: the two schedules agree to 2e-7 m, solve and polish the same QPs, two groups of
+    missions give the same bits as one; a round budget that does not finish a mission is RBP_ERR_QP_FAILED"""
+    import os
+    import subprocess
+    import sys
+    dev = os.path.join(A.LIB_DIR, "librbp_hip_dev.so")
+    assert os.path.exists(dev), "lib/librbp_hip_dev.so is missing: __graft_entry__.build() (make dev) builds it"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/phase_split_cases.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=root,
+                       env={**os.environ, "RBP_HIP_LIB": dev}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_reduced_row_set_is_the_same_optimum_for_any_radius():

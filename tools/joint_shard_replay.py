@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--map", type=int, default=1)
     ap.add_argument("--xgmi-gbs", type=float, default=100.0, help="model only: bytes/s one direction of the pair's link sustains (a link's peak is ~153 GB/s)")
     ap.add_argument("--xchg-us", type=float, default=60.0, help="model only: latency of one two-rank collective on top of the hook's own cost")
+    ap.add_argument("--stream", action="store_true", help="replay through the STREAM-ORDERED exchange (rbp_session_shard_joint_stream): the hook enqueues the "
+                                                          "copy of the recording on the run's stream, nothing synchronises per exchange")
     args = ap.parse_args()
     if args.agents == 256:
         p = Param.test_sweep(world_x_min=-5, world_y_min=-5, world_x_max=15, world_y_max=5, sequential=False)
@@ -135,9 +137,25 @@ def main():
             hook_s[0] += time.perf_counter() - t0
             return 0
 
-        hk = planner.EXCHANGE_FN(replay)
+        def replay_stream(user, send_ptr, recv_ptr, nbytes, stream_ptr, r=r, pos=pos, hook_s=hook_s):
+            t0 = time.perf_counter()
+            got = rec[r][pos[0]]
+            pos[0] += 1
+            if got.numel() * 8 != nbytes:
+                return 3
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream_ptr)) if stream_ptr else torch.cuda.default_stream()):
+                dev(recv_ptr, nbytes).copy_(got, non_blocking=True)
+            hook_s[0] += time.perf_counter() - t0
+            return 0
+
         s, pl = session()
-        assert L.rbp_session_shard_joint(s._h, r, 2, hk, None) == 0
+        if args.stream:
+            import ctypes as C
+            hk = planner.EXCHANGE_STREAM_FN(replay_stream)
+            assert L.rbp_session_shard_joint_stream(s._h, r, 2, C.cast(hk, C.c_void_p), None, None, 600.0) == 0
+        else:
+            hk = planner.EXCHANGE_FN(replay)
+            assert L.rbp_session_shard_joint(s._h, r, 2, hk, None) == 0
         timed_run(s)          # warm-up (also replays)
         s.reset()
         pos[0] = 0
@@ -150,6 +168,10 @@ def main():
         out[f"rank{r}_same_bits_as_unsharded"] = same(pl, alone)
     wire = out["exchange_bytes_each_way"] / (args.xgmi_gbs * 1e9) + out["exchanges"] * args.xchg_us * 1e-6
     slow = max(out["rank0_alone_replayed_s"], out["rank1_alone_replayed_s"])
+    out["exchange"] = "stream-ordered (one host synchronisation per interior-point round)" if args.stream else "synchronous hook (a host synchronisation per exchange)"
+    if args.stream:
+        args.xchg_us = min(args.xchg_us, 20.0)  # (no host round trip per exchange: what is left is the collective's own latency on the stream)
+    wire = out["exchange_bytes_each_way"] / (args.xgmi_gbs * 1e9) + out["exchanges"] * args.xchg_us * 1e-6
     out["model"] = {"what": "slower replayed rank + bytes / link bandwidth + exchanges x collective latency: an ESTIMATE of the two-GPU time, not a measurement",
                     "xgmi_gbs_assumed": args.xgmi_gbs, "collective_latency_us_assumed": args.xchg_us, "wire_s": wire,
                     "two_gpu_s_estimated": slow + wire, "speedup_estimated": t_alone / (slow + wire)}
