@@ -27,4 +27,9 @@ for N in 1 2 4 8; do
     else python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((port++)) bench.py --config c4 $J --gpus $N --steps 2 | tail -1 >> $OUT; fi
   done
 done
+# the same joint solve with NO torch in the solve's process: lib/rbp_c4_joint_rank per rank, rank pairs over the stream-ordered RCCL exchange
+for N in 2 4 8; do
+  [ "$N" -gt "$NGPU" ] && continue
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((port++)) bench.py --config c4 --joint --native-pair --gpus $N --steps 2 | tail -1 >> $OUT
+done
 echo "wrote $OUT"
