@@ -2632,9 +2632,11 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
     // sweeps read (s, z) three times and write them once (64 B), frozen rows also read their constant three times (+24 B); per free
     // control point the accumulators are written twice and read four times (288 B); the knot blocks: on the tiled path 8 block
     // transfers of ldb^2 doubles per knot (T_j written and read, two factor blocks written once and read by both substitutions); on the
-    // wave path (round 3) T_j is written and read as a triangle and the knot's factor is ONE triangle, M_j = L_j^-T, written once and
-    // staged four times (forward and backward pass of the two substitutions), plus the reciprocal pivots: 7 triangles + 5 nk
-    const double blk_doubles = d.nk <= 36 ? 7.0 * (d.nk * (d.nk + 1) / 2) + 5.0 * d.nk : 8.0 * d.ldb * d.ldb;
+    // wave path the knot's factor is ONE triangle, M_j = L_j^-T, written once and staged four times (forward and backward pass of the two
+    // substitutions), plus the reciprocal pivots: 5 triangles + 5 nk.  (Until round 6 the model also counted T_j written and read as a
+    // triangle -- 7 triangles -- which both builds have stopped doing: the blocks are assembled just in time into LDS images and never
+    // reach global memory, so those bytes are no longer part of what the algorithm has to move.)
+    const double blk_doubles = d.nk <= 36 ? 5.0 * (d.nk * (d.nk + 1) / 2) + 5.0 * d.nk : 8.0 * d.ldb * d.ldb;
     const double bytes_sweeps = 88.0 * frozen_free_rows + 64.0 * (double)(d.oq - 6) * (6.0 * d.nb + 2.0 * d.npb) + 288.0 * (double)d.nb * (d.oq - 6);
     const double bytes_iter = bytes_sweeps + 8.0 * (double)d.nj * blk_doubles;
     PolishWs pw;
