@@ -3353,7 +3353,17 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 6; ++j) cd[i][n - j] = (i <= j) ? coef_derivative(i, j) * cf[n - j] : 0.0;
             const double dt = T[m + 1] - T[m];
-            {  // scale_to_max_vel :756-794, under both root rules
+            // Shortcut (round 6, when both root rules became part of every run): a Bezier curve stays inside the hull of its control points, so
+            // |velocity| <= 5 max |c_{i+1} - c_i| / dt and |acceleration| <= 20 max |c_{i+2} - 2 c_{i+1} + c_i| / dt^2 on the whole segment.
+            // A segment whose bound is inside the limit (with a margin far above what the power-basis sums below can differ by) scales by 1
+            // under either rule, whatever its roots: no root finding, no eigenvalues.  Everything else takes the reference's path unchanged.
+            const double* cp = s.ctrl + (size_t)mission * N * 3 * 6 * MS + ((size_t)qi * 3 + k) * oq + 6 * m;
+            double vb = 0, ab = 0;
+            for (int i = 0; i < 5; ++i) vb = fmax(vb, fabs(cp[i + 1] - cp[i]));
+            for (int i = 0; i < 4; ++i) ab = fmax(ab, fabs(cp[i + 2] - 2 * cp[i + 1] + cp[i]));
+            const bool vel_inside = vb * (5.0 / dt) * (1 + 1e-9) <= s.max_vel[((size_t)mission * N + qi) * 3 + k];
+            const bool acc_inside = ab * (20.0 / (dt * dt)) * (1 + 1e-9) <= s.max_acc[((size_t)mission * N + qi) * 3 + k];
+            if (!vel_inside) {  // scale_to_max_vel :756-794, under both root rules
                 double r0[3], r1[3];
                 const int n0 = real_roots(cd[2], 3, r0), n1 = first_eigen_roots(cd[2], 3, 2, r1);  // roots_derivative(2, coef_der) :761
                 const double lim = s.max_vel[((size_t)mission * N + qi) * 3 + k];
@@ -3364,7 +3374,7 @@ __global__ __launch_bounds__(256) void timescale_kernel(DevSession s) {
                 if (ts < sc0) ts = sc0;
                 if (ts1 < sc1) ts1 = sc1;
             }
-            {  // scale_to_max_acc :797-847
+            if (!acc_inside) {  // scale_to_max_acc :797-847
                 const double a = cd[3][0], b = cd[3][1], cc = cd[3][2], D = b * b - 4 * a * cc;
                 double tsx[4] = {0, dt, 0, 0};
                 int nt = 2;
