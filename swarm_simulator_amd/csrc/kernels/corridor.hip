@@ -20,7 +20,10 @@
 #include "rbp_dev.h"
 
 // SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
-#define SFC_WAVES 8         // agents (wavefronts) per workgroup, sharing one occupancy bitmask in LDS
+#define SFC_WAVES 8         // wavefronts per workgroup (one agent each at a time), sharing one occupancy bitmask in LDS
+#ifndef SFC_AGENT_ROUNDS
+#define SFC_AGENT_ROUNDS 8  // large sessions: a workgroup's waves work through SFC_WAVES * SFC_AGENT_ROUNDS agents (see sfc_kernel)
+#endif
 typedef short sfc_key_t;             // a voxel index along one axis (< 4096), -1 outside the grid
 typedef unsigned short sfc_log_t;    // box_log entries: a run length of waypoints (<= M + 1)
 
@@ -373,15 +376,22 @@ __global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
 #ifndef SFC_WAVES_PER_EU
 #define SFC_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(DevSession s) {
+// apw = agents per workgroup (a multiple of SFC_WAVES).  apw == SFC_WAVES: one agent per wave, as many workgroups in flight as possible (small
+// sessions: a lone mission is eight workgroups on eight CUs).  apw > SFC_WAVES (round 6, sessions of several rounds of workgroups): the
+// wavefronts of a workgroup TAKE the agents of its range one after the other from a counter in LDS -- an agent's corridor takes anything from
+// 40 to 200 us, and with one agent per wave a workgroup (its LDS, its wave slots) lived as long as its slowest agent while the other seven
+// slots idled; now a wave that is done starts the next agent.  Which wave grows which agent's boxes changes nothing about them.
+__global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(DevSession s, int apw) {
 #ifdef SFC_PROFILE
     const long long t_start = wall_clock64();
 #endif
-    const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
+    const int groups = (s.agent_end - s.agent_begin + apw - 1) / apw;
     // the wave index is wave-uniform by construction; as a plain threadIdx expression the compiler must treat it (and the agent index, every
     // pointer and the whole box state derived from it) as divergent, i.e. keep them in vector registers
     const int mission = blockIdx.x / groups, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int qi = s.agent_begin + (blockIdx.x % groups) * SFC_WAVES + wave;
+    const int a_lo = s.agent_begin + (blockIdx.x % groups) * apw, a_hi = a_lo + apw < s.agent_end ? a_lo + apw : s.agent_end;
+    __shared__ int next_agent;  // next agent of [a_lo, a_hi) nobody has taken yet (the first SFC_WAVES go to the waves by index)
+    if (threadIdx.x == 0) next_agent = SFC_WAVES;
     const int M = s.Mk[mission], P = M + 1, PS = s.M + 1, MB = s.max_boxes, MBcap = s.MBk[mission];  // PS, MB: slot strides
     // LDS: [occupancy mask: s.sfc_mask_words words][per wave: key lists x | y | z, three slab lists][per wave: box_log [MB][P]]
     extern __shared__ __attribute__((aligned(16))) unsigned sfc_lds[];
@@ -401,10 +411,17 @@ __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(D
         for (unsigned i = threadIdx.x; i < nq; i += 64 * SFC_WAVES) ((uint4*)mask)[i] = gm[i];
     }
     __syncthreads();
-    if (qi >= s.agent_end) return;
     // what the key lists hold (extent, count, z summary) lives in LDS beside them: wave-uniform state that is read once per box test
     // has no business occupying 42 vector registers for the whole kernel
     __shared__ AxisCache caches[SFC_WAVES][6];
+    for (int take = wave;; ) {
+    const int qi = a_lo + take;
+    if (qi >= a_hi) return;
+    {  // the agent after this one (taken now: the atomic's round trip hides behind the set-up below)
+        int nx = 0;
+        if (lane == 0) nx = atomicAdd(&next_agent, 1);
+        take = __builtin_amdgcn_readfirstlane(nx);
+    }
     SfcCtx c;
     c.cache = caches[wave], c.slab = caches[wave] + 3;
     c.grid = w.dist;
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(D
     }
     if (err) {
         if (lane == 0) atomicCAS(&s.status[mission], 0, err);
-        return;
+        continue;
     }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
@@ -478,10 +495,12 @@ __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(D
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // box_log is private to this wave
     __builtin_amdgcn_wave_barrier();
+    for (int b = lane; b < nbox; b += 64)  // the running counts: one box per lane
+        for (int j = 1; j < P; ++j)
+            if (box_log[b * P + j]) box_log[b * P + j] = box_log[b * P + j - 1] + 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        for (int b = 0; b < nbox; ++b)
-            for (int j = 1; j < P; ++j)
-                if (box_log[b * P + j]) box_log[b * P + j] = box_log[b * P + j - 1] + 1;
         // the time walk :212-237 (sequential)
         for (int b = 0; b < nbox; ++b) times[b] = -1;
         int box_iter = 0;
@@ -515,8 +534,11 @@ __global__ __launch_bounds__(64 * SFC_WAVES, SFC_WAVES_PER_EU) void sfc_kernel(D
         atomicAdd(&s.scalars[(size_t)mission * SC_N + 20], (double)c.t_keys);
         atomicAdd(&s.scalars[(size_t)mission * SC_N + 21], (double)c.t_samp);
         atomicAdd(&s.scalars[(size_t)mission * SC_N + 22], (double)(wall_clock64() - t_after_mask));
-        atomicAdd(&s.scalars[(size_t)mission * SC_N + 23], (double)(t_after_mask - t_start));
+        if (qi == a_lo + wave) atomicAdd(&s.scalars[(size_t)mission * SC_N + 23], (double)(t_after_mask - t_start));
 #endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the next agent reuses this wave's key lists and box_log
+    __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -603,11 +625,16 @@ int launch_corridor(const DevSession& s, hipStream_t st) {
     // updateObsBox() && updateRelBox() (:25): RSFC results are only meaningful if SFC succeeded; status keeps the
     // first error, with SFC errors taking precedence because sfc_kernel is enqueued first.
     const size_t lds = corridor_lds_bytes(s);
-    const int groups = (s.agent_end - s.agent_begin + SFC_WAVES - 1) / SFC_WAVES;
+    // agents per workgroup: sessions whose one-agent-per-wave grid would be more than two rounds of workgroups on the chip let the waves
+    // take agents from a counter (sfc_kernel); smaller ones keep every agent on a wave of its own, all in flight at once
+    const int nag = s.agent_end - s.agent_begin;
+    const long long wg8 = (long long)s.K * ((nag + SFC_WAVES - 1) / SFC_WAVES);
+    const int apw = wg8 > 1024 ? SFC_WAVES * SFC_AGENT_ROUNDS : SFC_WAVES;
+    const int groups = (nag + apw - 1) / apw;
     if (hipFuncSetAttribute((const void*)sfc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return rbp_set_error(RBP_ERR_HIP, "sfc_kernel: the dynamic LDS it needs was refused by the device");
     if (groups > 0) hipLaunchKernelGGL(mask_kernel, dim3(SFC_MASK_BLOCKS, s.K), dim3(256), 0, st, s);
-    if (groups > 0) hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s);
+    if (groups > 0) hipLaunchKernelGGL(sfc_kernel, dim3(s.K * groups), dim3(64 * SFC_WAVES), lds, st, s, apw);
     const long long total = (long long)s.K * s.npair * s.M;
     if (total > 0) hipLaunchKernelGGL(rsfc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s);
     return RBP_OK;

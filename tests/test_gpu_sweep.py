@@ -278,3 +278,53 @@ def test_resident_copies_of_a_mission_agree_bit_for_bit():
             assert np.array_equal(it, first[0])
             assert all(np.array_equal(a.view(np.uint64), b.view(np.uint64)) for a, b in zip(ctrl, first[1]))
     s.close()
+
+
+def test_corridor_of_a_large_session_equals_the_small_sessions():
+    """sessions of more than two rounds of workgroups run sfc_kernel with its wavefronts TAKING the agents of a mission from a counter
+    (kernels/corridor.hip, round 6) instead of one agent per wave: 130 missions (10 maps x 13 copies, mixed radii in every third copy) against
+    the same missions in sessions of 10 -- boxes, counts, end times, relative normals bit for bit, the same number of distance samples; then
+    an agent RANGE of the large session (what one rank of an agent-sharded corridor runs) against the full run"""
+    p = Param.test_sweep()
+    m = host.load_mission("mission_64agents_15.json")
+    import copy
+    m2 = copy.deepcopy(m)
+    m2.radius = m.radius.copy()
+    m2.radius[::5] *= 0.8   # agents with another radius read the float grid instead of the occupancy mask
+    maps = [1, 4, 7, 12, 19, 23, 31, 38, 44, 50]
+    worlds = [host.load_world(f"map{i}.bt", p) for i in maps]
+    inits = [host.ecbs_plan(w, m, p) for w in worlds]
+    small = {}
+    for mis, tag in ((m, 0), (m2, 1)):
+        plans = [g.clone_inputs() for g in inits]
+        s = planner.Session(worlds, [mis] * len(maps), p, plans)
+        s.run(A.RBP_STAGE_CORRIDOR)
+        assert s.download() == [0] * len(maps)
+        small[tag] = (plans, int(s.counters()["sfc_samples"]))
+        s.close()
+    copies = 13
+    kinds = [1 if c % 3 == 2 else 0 for c in range(copies)]
+    big_worlds = worlds * copies
+    big_missions = [m2 if kinds[c] else m for c in range(copies) for _ in maps]
+    big_plans = [g.clone_inputs() for c in range(copies) for g in inits]
+    assert len(big_plans) * 8 > 1024, "the session must be large enough for the agents-from-a-counter grid"
+    s = planner.Session(big_worlds, big_missions, p, big_plans)
+    s.run(A.RBP_STAGE_CORRIDOR)
+    assert s.download() == [0] * len(big_plans)
+    assert int(s.counters()["sfc_samples"]) == sum(small[k][1] for k in kinds)
+    for c in range(copies):
+        for i in range(len(maps)):
+            g, r = big_plans[c * len(maps) + i], small[kinds[c]][0][i]
+            tag = f"copy {c} map{maps[i]}"
+            assert np.array_equal(g.sfc_count, r.sfc_count) and np.array_equal(g.sfc_box, r.sfc_box) and np.array_equal(g.sfc_time, r.sfc_time), tag
+            assert np.array_equal(bits(g.rsfc_normal), bits(r.rsfc_normal)), tag
+    full = [(g.sfc_count.copy(), g.sfc_box.copy(), g.sfc_time.copy()) for g in big_plans]
+    for b, e in ((16, 40), (0, 9), (57, 64)):
+        s.reset()
+        s.set_agent_range(b, e)
+        s.run(A.RBP_STAGE_CORRIDOR)
+        s.set_agent_range(0, m.qn)
+        assert s.download() == [0] * len(big_plans)
+        for g, (cnt, box, tim) in zip(big_plans, full):
+            assert np.array_equal(g.sfc_count[b:e], cnt[b:e]) and np.array_equal(g.sfc_box[b:e], box[b:e]) and np.array_equal(g.sfc_time[b:e], tim[b:e]), (b, e)
+    s.close()
