@@ -20,7 +20,9 @@
 #include "rbp_dev.h"
 
 // SFC_MAXS (max samples per axis) is defined in rbp_dev.h: rbp_session_create rejects worlds/resolutions that exceed it
+#ifndef SFC_WAVES
 #define SFC_WAVES 8         // wavefronts per workgroup (one agent each at a time), sharing one occupancy bitmask in LDS
+#endif
 #ifndef SFC_AGENT_ROUNDS
 #define SFC_AGENT_ROUNDS 8  // large sessions: a workgroup's waves work through SFC_WAVES * SFC_AGENT_ROUNDS agents (see sfc_kernel)
 #endif
@@ -374,7 +376,9 @@ __global__ __launch_bounds__(256) void mask_kernel(DevSession s) {
 }
 
 #ifndef SFC_WAVES_PER_EU
+#ifndef SFC_WAVES_PER_EU
 #define SFC_WAVES_PER_EU 4
+#endif
 #endif
 // apw = agents per workgroup (a multiple of SFC_WAVES).  apw == SFC_WAVES: one agent per wave, as many workgroups in flight as possible (small
 // sessions: a lone mission is eight workgroups on eight CUs).  apw > SFC_WAVES (round 6, sessions of several rounds of workgroups): the

@@ -94,6 +94,9 @@
 #endif
 #define QP_STAGE_BUFS (QP_THREADS >= 512 ? QP_STAGE_BUFS_BIG : 2)  // (the 256-thread build shares a CU's LDS between two workgroups)
 #endif
+#ifndef QP_STAGE_REGS
+#define QP_STAGE_REGS (QP_THREADS >= 512 ? 0 : 2)  // register sets of a staging thread whose loads stay in flight across step barriers (solve_staged; 0 = load and store within one step): the 256-thread build, whose missions share the memory system with 511 others
+#endif
 #ifndef QP_RCP_NEWTON
 #define QP_RCP_NEWTON 2
 #endif
@@ -1676,6 +1679,33 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             if (doff[u] >= 0 && (right ? jr >= 0 : jl >= 0)) buf[doff[u]] = tmp[u];
         }
     };
+    // (round 6) the same in two halves, so that a staging thread's loads can stay in flight ACROSS step barriers: under full load a trip to global
+    // memory (3-5 us) is longer than a chain step (~1.5 us), and a staging wave that loads, waits and stores inside one step made every
+    // step as long as that trip however many stage buffers there were (which is why a third buffer never paid).  With QP_STAGE_REGS = R
+    // register sets the loads of step s + QP_STAGE_BUFS - 1 + R are issued at step s and stored R steps later.
+    auto stage_load = [&](int s, double (&tmp)[MAXE]) {
+        if (s >= nsteps) return;
+        const int jl = left_j(s), jr = right_j(s);
+        // (explicitly GLOBAL loads and LDS stores: through generic pointers they are flat instructions, which count on both memory counters
+        // and make the compiler wait for ALL of them at the first use -- no load would stay in flight across a barrier)
+        typedef __attribute__((address_space(1))) const double gdbl;
+        gdbl* srcl = (gdbl*)(w.Lf + (size_t)(jl >= 0 ? jl : 0) * KF_STRIDE(NK));
+        gdbl* srcr = (gdbl*)(w.Lf + (size_t)(jr >= 0 ? jr : 0) * KF_STRIDE(NK));
+        // no predicates: a load nobody needs reads a valid address (soff = 0, knot 0) and is never stored -- straight-line loads are what
+        // lets the compiler count them (s_waitcnt vmcnt(n), n > 0) instead of waiting for all
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) tmp[u] = (doff[u] >= SCH ? srcr : srcl)[soff[u]];
+    };
+    auto stage_store = [&](int s, const double (&tmp)[MAXE], double* buf) {
+        if (s >= nsteps) return;
+        const int jl = left_j(s), jr = right_j(s);
+        kl_lds* bl = (kl_lds*)buf;
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const bool right = doff[u] >= SCH;
+            if (doff[u] >= 0 && (right ? jr >= 0 : jl >= 0)) bl[doff[u]] = tmp[u];
+        }
+    };
     if (ROLE == 1)
         for (int s0 = 0; s0 < QP_STAGE_BUFS - 1 && s0 < nsteps; ++s0) stage(s0, lds + s0 * STG);
     __syncthreads();
@@ -1702,17 +1732,71 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     };
     double cf0, cf1, cf2;
     step_coef(0, cf0, cf1, cf2);
-#ifdef QP_SOLVE_TIMERS  // developer build: left chain wave, SC 25 = work of the steps, 26 = waiting at the step barrier, 27 = steps
+#ifdef QP_SOLVE_TIMERS  // developer build: left chain wave, SC 25 = work of the steps, 26 = waiting at the step barrier (staging wave: 29 / 30, right chain: 33 / 34)
     long long st_ = wall_clock64();
 #define SOLVE_T(slot)                                                              \
     do {                                                                           \
         const long long t_ = wall_clock64();                                       \
-        if (ROLE == 0 && w.prof && tid == 0) w.prof[slot] += (double)(t_ - st_);   \
+        const int who_ = ROLE == 0 ? (tid == 0 ? 0 : (tid == 64 ? 8 : -1)) : (tid == 128 ? 4 : -1); /* left chain 25/26, staging wave 29/30, right chain 33/34 */ \
+        if (w.prof && who_ >= 0) w.prof[slot + who_] += (double)(t_ - st_);        \
         st_ = t_;                                                                  \
     } while (0)
 #else
 #define SOLVE_T(slot)
 #endif
+    if (ROLE == 1 && QP_STAGE_REGS > 0) {
+        constexpr int R = QP_STAGE_REGS > 0 ? QP_STAGE_REGS : 1;
+        double tq[R][MAXE];
+#pragma unroll
+        for (int k = 0; k < R; ++k) stage_load(QP_STAGE_BUFS - 1 + k, tq[k]);
+        // steady state, straight-line (no predicate, no branch between a load and its store: only then does the compiler count the loads in
+        // flight instead of waiting for all of them): every element is stored -- the ones a thread does not have go to a padding column
+        // nobody's products see (row 0, column KL_LD - 1, times the zero padding of the vectors), a chain that idles at a step gets knot 0's
+        // numbers into its half of the buffer, which it does not read
+        int dsto[MAXE];
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) dsto[u] = doff[u] >= 0 ? doff[u] : KL_LD - 1;
+        typedef __attribute__((address_space(1))) const double gdbl;
+        // The loads of the NEXT R steps are issued at the top of an iteration and first touched at its bottom, R step barriers later: the
+        // compiler drains the memory counter completely wherever a loop-carried load is used (it does not count across a back edge), so the
+        // one place where everything must have landed is made to be the place where it drains.
+        double nq[R][MAXE];
+        int s = 0;
+        for (; s + 2 * R + QP_STAGE_BUFS - 1 <= nsteps; s += R) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int sl = s + R + k + QP_STAGE_BUFS - 1;
+                const int jl = left_j(sl), jr = right_j(sl);
+                gdbl* srcl = (gdbl*)(w.Lf + (size_t)(jl >= 0 ? jl : 0) * KF_STRIDE(NK));
+                gdbl* srcr = (gdbl*)(w.Lf + (size_t)(jr >= 0 ? jr : 0) * KF_STRIDE(NK));
+#pragma unroll
+                for (int u = 0; u < MAXE; ++u) nq[k][u] = (doff[u] >= SCH ? srcr : srcl)[soff[u]];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int sp = s + k + QP_STAGE_BUFS - 1;
+                kl_lds* bl = (kl_lds*)(lds + (sp % QP_STAGE_BUFS) * STG);
+#pragma unroll
+                for (int u = 0; u < MAXE; ++u) bl[dsto[u]] = tq[k][u];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+#pragma unroll
+                for (int u = 0; u < MAXE; ++u) tq[k][u] = nq[k][u];
+        }
+        for (; s < nsteps; s += R) {  // the last few steps (loads or stores that do not exist any more: predicated)
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (s + k < nsteps) {  // (uniform: every thread of the workgroup passes nsteps barriers, here or in the chains' loop)
+                    const int sp = s + k + QP_STAGE_BUFS - 1;
+                    stage_store(sp, tq[k], lds + (sp % QP_STAGE_BUFS) * STG);
+                    stage_load(sp + R, tq[k]);
+                    __syncthreads();
+                }
+            }
+        }
+    } else
     for (int s = 0; s < nsteps; ++s) {
         SOLVE_T(26);
         const double e0 = cf0, e1 = cf1, e2 = cf2;

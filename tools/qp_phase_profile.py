@@ -29,3 +29,7 @@ for i, n in enumerate(["polish: candidates+K0+gradient", "polish: V columns + S"
 print(f"  left chain: MFMA update {sc[:, 25].mean() / 1e5:.2f} ms, waiting for block assembly {sc[:, 26].mean() / 1e5:.2f} ms, knot work {sc[:, 27].mean() / 1e5:.2f} ms")
 if os.environ.get("LHSTATS"):
     print(f"  LH calls {sc[:, 27].mean():.1f}  appends {sc[:, 25].mean():.1f}  gradient passes {sc[:, 24].mean():.1f} (slot shared with the byte counter: subtract it)  inner solves {sc[:, 26].mean():.1f} per mission")
+if os.environ.get("SOLVE_TIMERS"):  # library built with EXTRA="-DQP_SOLVE_TIMERS" (the slots of the chain-side timers then hold the substitutions' instead)
+    sc = s.scalars(36)
+    for who, a, b in (("left chain ", 25, 26), ("right chain", 33, 34), ("staging wave", 29, 30)):
+        print(f"  substitutions, {who}: work {sc[:, a].mean() / 1e5:.2f} ms, at the step barrier {sc[:, b].mean() / 1e5:.2f} ms")
