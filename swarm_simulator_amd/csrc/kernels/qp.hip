@@ -56,6 +56,21 @@
 #ifndef QP_ROW_PF
 #define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
 #endif
+#ifndef QP_BLK_PRE
+#define QP_BLK_PRE 1
+#endif
+#ifndef QP_BLK_MASK
+#define QP_BLK_MASK 0x10E  // the passes (bit = PASS_*) that stream in blocks: the four sweeps of the interior-point loop (BUILD, AFF, STEP, UPBUILD)
+#endif
+#ifndef QP_ROW_BLK
+#define QP_ROW_BLK (QP_THREADS >= 512 ? 0 : 4)  // (round 6) frozen-row stream in BLOCKS of this many rows whose loads are issued a block ahead (see row_pass); 0 = off.
+                                             // The 256-thread build (missions that share the memory system with 511 others); A/B 3 / 4 / 5 / 6: 4
+#endif
+// a generic pointer into the workspace as the GLOBAL pointer it is: loads / stores through it are global_* instructions (one memory counter,
+// counted in order) instead of flat_* (both counters, and the compiler waits for every outstanding access at the first use of any)
+#define QG(p) ((__attribute__((address_space(1))) double*)(p))
+#define QGC(p) ((__attribute__((address_space(1))) const double*)(p))
+#define QGF(p) ((__attribute__((address_space(1))) const float*)(p))
 #ifndef QP_FAR_SLACK
 // REDUCED ROW SET of the interior-point phase (round 5).  A frozen-neighbour row whose slack at the batch QP's starting point exceeds this
 // many metres for all six control points of its (agent, segment) group is FAR: the interior-point sweeps do not walk it (no (s, z), no
@@ -448,7 +463,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         w.s[r] = s;
         w.z[r] = io.mu0 / s;
     } else if (PASS == PASS_BUILD) {
-        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
+        const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         const double rg = s - slack;
         wgt = z * fast_rcp(s + io.dreg * z);  // = 1 / (s/z + dreg)
         v = -wgt * (rg - s);                  // predictor: rc / z = s
@@ -456,7 +471,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         io.sum0 += cw * s * z;
         io.vmax = fmax(io.vmax, fabs(rg));
     } else if (PASS == PASS_AFF) {
-        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
+        const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
@@ -471,7 +486,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         v = -wgt * (rg - s - cc * iz);
         wgt = wgt * iz;
     } else if (PASS == PASS_STEP) {
-        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
+        const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         const double rg = s - slack;
         const double iz = fast_rcp(z), is = fast_rcp(s);
         wgt = z * fast_rcp(s + io.dreg * z);
@@ -483,7 +498,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         io.vmax = fmax(io.vmax, fmax(-ds * is, -dz * iz));
     } else if (PASS == PASS_UPBUILD) {
         // old state (s, z) at the old point: slack_old = slack + alpha * gd
-        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
+        const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         const double rg = s - (slack + io.alpha * gd);
         const double iz = fast_rcp(z);
         const double w0 = z * fast_rcp(s + io.dreg * z);
@@ -493,7 +508,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
         const double dz = w0 * (gd + rg - rcc * iz);
         const double ds = -(rcc + s * dz) * iz;
         const double sn = s + io.alpha * ds, zn = z + io.alpha * dz;
-        w.s2[r] = sn, w.z2[r] = zn;
+        QG(w.s2)[r] = sn, QG(w.z2)[r] = zn;
         io.vmin = fmin(io.vmin, sn * zn);  // wide-neighbourhood test of the step just applied
         // ... and the next iteration's weights / residuals at the new point
         const double rgn = sn - slack;
@@ -505,7 +520,7 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
     } else if (PASS == PASS_PRESOLVE) {
         io.vmax = fmax(io.vmax, -slack);  // violation of a pinned (constant) row
     } else if (PASS == PASS_CAND) {
-        const double s = PRE ? s_in : w.s[r], z = PRE ? z_in : w.z[r];
+        const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         wgt = (z > s || s < 1e-6) ? fmax(z / s, 1e-300) : 0.0;  // candidate for the active set; the value orders the warm start
         w.cc[r] = wgt;
         v = slack;
@@ -564,6 +579,14 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
         // ---- bound rows (idx 0..5)
+        // (QP_ROW_BLK: their (s, z) are requested together up front -- in the update sweep every row's stores stand between it and the
+        // next row's loads, which the compiler must not move across them)
+        constexpr bool pre_b = QP_ROW_BLK > 0 && QP_BLK_PRE && ((QP_BLK_MASK >> PASS) & 1) && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
+        double bs[6] = {0, 0, 0, 0, 0, 0}, bz[6] = {0, 0, 0, 0, 0, 0};
+        if (pre_b) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bs[e] = QGC(w.s)[base + (size_t)e * 64], bz[e] = QGC(w.z)[base + (size_t)e * 64];
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double hi = w.boxhi[((size_t)a * M + seg) * 3 + k], lo = w.boxlo[((size_t)a * M + seg) * 3 + k];
@@ -573,7 +596,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
                 const double sg = side == 0 ? 1.0 : -1.0;
                 const double slack = side == 0 ? hi - xa[k] : xa[k] - lo;
                 double wgt = 0, v = 0, zo = 0;
-                row_op<PASS>(slack, sg * da[k], sg * dd[k], r, w, io, 1.0, wgt, v, zo);
+                row_op<PASS, pre_b>(slack, sg * da[k], sg * dd[k], r, w, io, 1.0, wgt, v, zo, bs[2 * k + side], bz[2 * k + side]);
                 if (cand && wgt != 0)
                     emit_cand(d, w, *c.pw, r, j6, a, -1, k == 0 ? sg : 0.0, k == 1 ? sg : 0.0, k == 2 ? sg : 0.0, slack,
                               (int)(((size_t)qa * 3 + k) * oq + j6), side == 0 ? hi : lo, wgt);
@@ -643,6 +666,72 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         const int cnt = all_rows ? w.fcnt[grp] : cnt_near;
         const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
         const size_t r0 = base + (size_t)d.ncol0 * 64;
+        constexpr bool blk_path = QP_ROW_BLK > 0 && ((QP_BLK_MASK >> PASS) & 1);
+        if constexpr (blk_path) {
+        // Under load a trip to memory takes 3-5 us and a row's arithmetic 0.1: a thread that loads a row, works on it and stores it pays the
+        // trip once per row (the loads of the next row cannot move above the stores of this one, and the compiler drains the memory counter
+        // wherever a loop-carried load is used).  So the stream runs in BLOCKS: the (s, z), constant and normal of the NEXT QP_ROW_BLK rows
+        // are requested before the current block is worked on, and first touched -- copied -- after it: one trip per block, overlapped with
+        // the block's arithmetic.  Rows past the end re-read the last row (same cache lines) and are not used.  Same rows, same order, same
+        // arithmetic per row as the plain loop.
+        constexpr bool rd_sz = PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_CAND;
+        constexpr int B = QP_ROW_BLK > 0 ? QP_ROW_BLK : 1;
+        if (cnt > 0) {
+            double cs[B], cz[B], ch[B], ns[B], nz[B], nh[B];
+            float cn[B][3], nn[B][3];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int ix = u < cnt ? u : cnt - 1;
+                const size_t rx = r0 + (size_t)ix * 64;
+                cs[u] = rd_sz ? QGC(w.s)[rx] : 0.0, cz[u] = rd_sz ? QGC(w.z)[rx] : 0.0, ch[u] = QGC(w.rh)[rx];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) cn[u][e] = QGF(nr)[3 * ix + e];
+            }
+            for (int i0 = 0; i0 < cnt; i0 += B) {
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int ix = i0 + B + u < cnt ? i0 + B + u : cnt - 1;
+                    const size_t rx = r0 + (size_t)ix * 64;
+                    ns[u] = rd_sz ? QGC(w.s)[rx] : 0.0, nz[u] = rd_sz ? QGC(w.z)[rx] : 0.0, nh[u] = QGC(w.rh)[rx];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) nn[u][e] = QGF(nr)[3 * ix + e];
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    const int idx = i0 + u;
+                    if (idx < cnt) {
+                        const size_t r = r0 + (size_t)idx * 64;
+                        if (PASS == PASS_CAND && idx >= cnt_near) {  // a far row: no (s, z); not a candidate unless a verification finds it violated
+                            QG(w.cc)[r] = 0.0;
+                        } else {
+                            const double n0 = cn[u][0], n1 = cn[u][1], n2 = cn[u][2];
+                            const double slack = ch[u] - (n0 * xa[0] + n1 * xa[1] + n2 * xa[2]);
+                            double wgt = 0, v = 0, zo = 0;
+                            row_op<PASS, rd_sz>(slack, n0 * da[0] + n1 * da[1] + n2 * da[2], n0 * dd[0] + n1 * dd[1] + n2 * dd[2], r, w, io, 1.0, wgt, v, zo, cs[u], cz[u]);
+                            if (cand && wgt != 0) emit_cand(d, w, *c.pw, r, j6, a, -1, n0, n1, n2, slack, -1, 0.0, wgt);
+                            if (accum) {
+                                if (build) {
+                                    S[0] += wgt * n0 * n0, S[1] += wgt * n0 * n1, S[2] += wgt * n0 * n2;
+                                    S[3] += wgt * n1 * n1, S[4] += wgt * n1 * n2, S[5] += wgt * n2 * n2;
+                                    gz[0] += zo * n0, gz[1] += zo * n1, gz[2] += zo * n2;
+                                    yv[0] += v * n0, yv[1] += v * n1, yv[2] += v * n2;
+                                } else {
+                                    S[0] += v * n0, S[1] += v * n1, S[2] += v * n2;
+                                    S[3] += wgt * n0, S[4] += wgt * n1, S[5] += wgt * n2;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    cs[u] = ns[u], cz[u] = nz[u], ch[u] = nh[u];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) cn[u][e] = nn[u][e];
+                }
+            }
+        }
+        } else {
 #if QP_ROW_PF > 0
         // Under load the stream is bound by the memory operations in flight per thread, and unrolling the (heavy) row arithmetic to get
         // more of them costs registers and instruction cache (unroll 4 measured 8 % slower than 2).  A prefetch ring decouples the two:
@@ -723,6 +812,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
             }
         }
 #endif
+        }
         if (accum) {
             double* acc = w.cpacc + it;
 #pragma unroll
