@@ -23,6 +23,7 @@
 // from the 3*nb coupled blocks inside a batch and from the K missions of a session.  The file is compiled twice
 // (512 / 256 threads per workgroup, see the note above planner_workspace_bytes).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "rbp_dev.h"
@@ -414,7 +415,17 @@ struct PassIO {
 #include "qp_polish.inc"
 #undef QP_POLISH_PART
 
+// (round 6) what a sweep looks up per control point before it can request anything -- its group, the group's row counts and normal offset,
+// its tile's first slot -- copied ONCE per batch QP into LDS (by rank, i.e. already through fperm): in global memory these were two dependent
+// trips per control point.  Only filled when the batch fits (wave path: nb <= 4); RowCtx::meta is null otherwise.
+#define QP_META_G 160
+struct SweepMeta {
+    unsigned short fbase[QP_META_G];
+    unsigned char grp[QP_META_G], near[QP_META_G], all[QP_META_G];
+    int tile_base[16];
+};
 struct RowCtx {
+    const SweepMeta* meta;  // LDS (see SweepMeta), or null: EVERY construction site sets it
     const PolishWs* pw;
     double* scal;  // this mission's diagnostic scalars (DevSession::scalars + mission * SC_N).  NOT a pointer to the DevSession:
                    // taking the kernel argument's address forces the whole struct into scratch memory
@@ -565,23 +576,60 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
     const int ncp = nb * oq;
     const int wi_stop = wi_end < ncp ? wi_end : ncp;
     for (int wi = wi0; wi < wi_stop; wi += stride) {
-        const int grp = w.fperm[wi / 6], a = grp / M, seg = grp - a * M, i = wi % 6, j6 = 6 * seg + i, it = a * oq + j6;
+        constexpr bool pre_b = QP_ROW_BLK > 0 && QP_BLK_PRE && ((QP_BLK_MASK >> PASS) & 1) && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
+        constexpr bool all_rows = (PASS == PASS_PRESOLVE || PASS == PASS_VERIFY || PASS == PASS_CAND_GEO || PASS == PASS_CAND);
+        const __attribute__((address_space(3))) SweepMeta* mt = pre_b ? (const __attribute__((address_space(3))) SweepMeta*)c.meta : nullptr;
+        int grp, cnt_near, cnt_all, fb;
+        size_t base;
+        if (pre_b && mt) {  // (uniform) the look-ups from LDS
+            const int rk = wi / 6;
+            grp = mt->grp[rk], cnt_near = mt->near[rk], cnt_all = mt->all[rk], fb = mt->fbase[rk];
+            base = (size_t)mt->tile_base[wi >> 6] + (wi & 63);
+        } else {
+            grp = w.fperm[wi / 6];
+            cnt_near = w.fnear[grp], cnt_all = all_rows ? w.fcnt[grp] : cnt_near, fb = w.fbase[grp];
+            base = (size_t)w.tile_base[wi >> 6] + (wi & 63);
+        }
+        const int a = grp / M, seg = grp - a * M, i = wi % 6, j6 = 6 * seg + i, it = a * oq + j6;
         const bool pinned = (j6 < 3 || j6 >= oq - 3);
         if (pinned != pinned_only) continue;
         const int qa = d.first + a;
-        const size_t base = (size_t)w.tile_base[wi >> 6] + (wi & 63);
         double xa[3], da[3], dd[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            xa[k] = c.ctrl[((size_t)qa * 3 + k) * oq + j6];
-            da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
-            dd[k] = need_dd ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            if (pre_b) {
+                xa[k] = QGC(c.ctrl)[((size_t)qa * 3 + k) * oq + j6];
+                da[k] = need_da ? QGC(w.dxa)[((size_t)a * 3 + k) * oq + j6] : 0.0;
+                dd[k] = need_dd ? QGC(w.dx)[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            } else {
+                xa[k] = c.ctrl[((size_t)qa * 3 + k) * oq + j6];
+                da[k] = need_da ? w.dxa[((size_t)a * 3 + k) * oq + j6] : 0.0;
+                dd[k] = need_dd ? w.dx[((size_t)a * 3 + k) * oq + j6] : 0.0;
+            }
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, yv[3] = {0, 0, 0}, gz[3] = {0, 0, 0};
+        const int cnt = all_rows ? cnt_all : cnt_near;
+        const float* nr = w.nrm + (size_t)fb * 3;
+        const size_t r0 = base + (size_t)d.ncol0 * 64;
+        // (QP_ROW_BLK) the first block of the frozen-row stream is requested here, with everything else the control point starts from
+        constexpr bool blk_path = QP_ROW_BLK > 0 && ((QP_BLK_MASK >> PASS) & 1);
+        constexpr bool rd_sz_b = PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_CAND;
+        constexpr int BB = QP_ROW_BLK > 0 ? QP_ROW_BLK : 1;
+        double cs[BB], cz[BB], ch[BB];
+        float cn[BB][3];
+        if (blk_path && cnt > 0) {
+#pragma unroll
+            for (int u = 0; u < BB; ++u) {
+                const int ix = u < cnt ? u : cnt - 1;
+                const size_t rx = r0 + (size_t)ix * 64;
+                cs[u] = rd_sz_b ? QGC(w.s)[rx] : 0.0, cz[u] = rd_sz_b ? QGC(w.z)[rx] : 0.0, ch[u] = QGC(w.rh)[rx];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) cn[u][e] = QGF(nr)[3 * ix + e];
+            }
+        }
         // ---- bound rows (idx 0..5)
         // (QP_ROW_BLK: their (s, z) are requested together up front -- in the update sweep every row's stores stand between it and the
         // next row's loads, which the compiler must not move across them)
-        constexpr bool pre_b = QP_ROW_BLK > 0 && QP_BLK_PRE && ((QP_BLK_MASK >> PASS) & 1) && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
         double bs[6] = {0, 0, 0, 0, 0, 0}, bz[6] = {0, 0, 0, 0, 0, 0};
         if (pre_b) {
 #pragma unroll
@@ -589,7 +637,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double hi = w.boxhi[((size_t)a * M + seg) * 3 + k], lo = w.boxlo[((size_t)a * M + seg) * 3 + k];
+            const double hi = pre_b ? QGC(w.boxhi)[((size_t)a * M + seg) * 3 + k] : w.boxhi[((size_t)a * M + seg) * 3 + k];
+            const double lo = pre_b ? QGC(w.boxlo)[((size_t)a * M + seg) * 3 + k] : w.boxlo[((size_t)a * M + seg) * 3 + k];
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const size_t r = base + (size_t)(2 * k + side) * 64;
@@ -614,32 +663,27 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
         // ---- in-batch pair rows (idx 6 .. 6 + nb - 2): canonical orientation n . (x_hi - x_lo) >= rr, so that the copy in the
         // other agent's column sees bit-identical inputs
-        for (int pb = 0; pb < nb - 1; ++pb) {
+        auto pair_row = [&](auto pre_tag, int pb, double n0, double n1, double n2, const double (&xb)[3], const double (&fa)[3], const double (&fd)[3],
+                            double rsum, double s_in, double z_in) {
+            constexpr bool PRE_P = decltype(pre_tag)::value;
             const int b = pb < a ? pb : pb + 1;
             const bool a_lo = a < b;
-            const int qb = d.first + b;
             const size_t r = base + (size_t)(6 + pb) * 64;
-            const float* nv = c.normals + (pair_index(N, a_lo ? qa : qb, a_lo ? qb : qa) * M + seg) * 3;
-            const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
-            double xb[3], gab = 0, gdb = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) xb[k] = c.ctrl[((size_t)qb * 3 + k) * oq + j6];
+            double gab = 0, gdb = 0;
             // e = x_hi - x_lo ; the G row is  n . x_lo - n . x_hi <= -rr
             const double e0 = a_lo ? xb[0] - xa[0] : xa[0] - xb[0], e1 = a_lo ? xb[1] - xa[1] : xa[1] - xb[1],
                          e2 = a_lo ? xb[2] - xa[2] : xa[2] - xb[2];
-            const double slack = n0 * e0 + n1 * e1 + n2 * e2 - (c.radius[qa] + c.radius[qb]);
+            const double slack = n0 * e0 + n1 * e1 + n2 * e2 - rsum;
             if (need_da) {
-                const double f0 = w.dxa[((size_t)b * 3 + 0) * oq + j6], f1 = w.dxa[((size_t)b * 3 + 1) * oq + j6],
-                             f2 = w.dxa[((size_t)b * 3 + 2) * oq + j6];
+                const double f0 = fa[0], f1 = fa[1], f2 = fa[2];
                 gab = a_lo ? n0 * (da[0] - f0) + n1 * (da[1] - f1) + n2 * (da[2] - f2) : n0 * (f0 - da[0]) + n1 * (f1 - da[1]) + n2 * (f2 - da[2]);
             }
             if (need_dd) {
-                const double f0 = w.dx[((size_t)b * 3 + 0) * oq + j6], f1 = w.dx[((size_t)b * 3 + 1) * oq + j6],
-                             f2 = w.dx[((size_t)b * 3 + 2) * oq + j6];
+                const double f0 = fd[0], f1 = fd[1], f2 = fd[2];
                 gdb = a_lo ? n0 * (dd[0] - f0) + n1 * (dd[1] - f1) + n2 * (dd[2] - f2) : n0 * (f0 - dd[0]) + n1 * (f1 - dd[1]) + n2 * (f2 - dd[2]);
             }
             double wgt = 0, v = 0, zo = 0;
-            row_op<PASS>(slack, gab, gdb, r, w, io, a_lo ? 1.0 : 0.0, wgt, v, zo);
+            row_op<PASS, PRE_P>(slack, gab, gdb, r, w, io, a_lo ? 1.0 : 0.0, wgt, v, zo, s_in, z_in);
             if (cand && wgt != 0 && a_lo) emit_cand(d, w, *c.pw, r, j6, a, b, n0, n1, n2, slack, -1, 0.0, wgt);
             if (accum) {
                 const double sg = a_lo ? 1.0 : -1.0;  // coefficient of x_a in the row is sg * n
@@ -656,17 +700,61 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
                     S[3] += ww * n0, S[4] += ww * n1, S[5] += ww * n2;
                 }
             }
+        };
+        if (pre_b && nb <= 4) {
+            // (QP_ROW_BLK) up to three pair rows: everything they read -- normal, the other agent's point and directions, radii, (s, z) -- is
+            // requested for all of them before the first is worked on (each cost two trips to memory, one after the other)
+            float pn[3][3];
+            double pxb[3][3], pfa[3][3], pfd[3][3], prs[3], pps[3], ppz[3];
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb) {
+                const int pq = pb < nb - 1 ? pb : 0;  // (a row that does not exist reads row 0's operands and is not worked on; nb = 1: nothing is)
+                const int b = nb > 1 ? (pq < a ? pq : pq + 1) : 0;
+                const bool a_lo = a < b;
+                const int qb = d.first + b;
+                const size_t r = base + (size_t)(6 + pq) * 64;
+                const size_t nvo = nb > 1 ? (pair_index(N, a_lo ? qa : qb, a_lo ? qb : qa) * M + seg) * 3 : 0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) pn[pb][e] = QGF(c.normals)[nvo + e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pxb[pb][k] = QGC(c.ctrl)[((size_t)qb * 3 + k) * oq + j6];
+                    pfa[pb][k] = need_da ? QGC(w.dxa)[((size_t)b * 3 + k) * oq + j6] : 0.0;
+                    pfd[pb][k] = need_dd ? QGC(w.dx)[((size_t)b * 3 + k) * oq + j6] : 0.0;
+                }
+                prs[pb] = QGC(c.radius)[qa] + QGC(c.radius)[qb];
+                pps[pb] = QGC(w.s)[r], ppz[pb] = QGC(w.z)[r];
+            }
+#pragma unroll
+            for (int pb = 0; pb < 3; ++pb)
+                if (pb < nb - 1)
+                    pair_row(std::true_type{}, pb, pn[pb][0], pn[pb][1], pn[pb][2], pxb[pb], pfa[pb], pfd[pb], prs[pb], pps[pb], ppz[pb]);
+        } else {
+            for (int pb = 0; pb < nb - 1; ++pb) {
+                const int b = pb < a ? pb : pb + 1;
+                const bool a_lo = a < b;
+                const int qb = d.first + b;
+                const float* nv = c.normals + (pair_index(N, a_lo ? qa : qb, a_lo ? qb : qa) * M + seg) * 3;
+                const double n0 = nv[0], n1 = nv[1], n2 = nv[2];
+                double xb[3], fa[3] = {0, 0, 0}, fd[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xb[k] = c.ctrl[((size_t)qb * 3 + k) * oq + j6];
+                const double rsum = c.radius[qa] + c.radius[qb];
+                if (need_da) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fa[k] = w.dxa[((size_t)b * 3 + k) * oq + j6];
+                }
+                if (need_dd) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fd[k] = w.dx[((size_t)b * 3 + k) * oq + j6];
+                }
+                pair_row(std::false_type{}, pb, n0, n1, n2, xb, fa, fd, rsum, 0.0, 0.0);
+            }
         }
         // ---- frozen neighbours that survived the presolve (rows implied by the SFC box of this segment are dropped): a stream
         // over the SELL arrays; the signed normal is shared by the six rows of the group
         // PRESOLVE / VERIFY / CAND_GEO see every row; the passes of the interior-point loop the near ones (the near rows come first in a
         // group's list); CAND walks all of them to clear the far rows' candidate marks
-        constexpr bool all_rows = (PASS == PASS_PRESOLVE || PASS == PASS_VERIFY || PASS == PASS_CAND_GEO || PASS == PASS_CAND);
-        const int cnt_near = w.fnear[grp];
-        const int cnt = all_rows ? w.fcnt[grp] : cnt_near;
-        const float* nr = w.nrm + (size_t)w.fbase[grp] * 3;
-        const size_t r0 = base + (size_t)d.ncol0 * 64;
-        constexpr bool blk_path = QP_ROW_BLK > 0 && ((QP_BLK_MASK >> PASS) & 1);
         if constexpr (blk_path) {
         // Under load a trip to memory takes 3-5 us and a row's arithmetic 0.1: a thread that loads a row, works on it and stores it pays the
         // trip once per row (the loads of the next row cannot move above the stores of this one, and the compiler drains the memory counter
@@ -675,18 +763,10 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         // the block's arithmetic.  Rows past the end re-read the last row (same cache lines) and are not used.  Same rows, same order, same
         // arithmetic per row as the plain loop.
         constexpr bool rd_sz = PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD || PASS == PASS_CAND;
-        constexpr int B = QP_ROW_BLK > 0 ? QP_ROW_BLK : 1;
+        constexpr int B = BB;
         if (cnt > 0) {
-            double cs[B], cz[B], ch[B], ns[B], nz[B], nh[B];
-            float cn[B][3], nn[B][3];
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                const int ix = u < cnt ? u : cnt - 1;
-                const size_t rx = r0 + (size_t)ix * 64;
-                cs[u] = rd_sz ? QGC(w.s)[rx] : 0.0, cz[u] = rd_sz ? QGC(w.z)[rx] : 0.0, ch[u] = QGC(w.rh)[rx];
-#pragma unroll
-                for (int e = 0; e < 3; ++e) cn[u][e] = QGF(nr)[3 * ix + e];
-            }
+            double ns[B], nz[B], nh[B];
+            float nn[B][3];
             for (int i0 = 0; i0 < cnt; i0 += B) {
 #pragma unroll
                 for (int u = 0; u < B; ++u) {
@@ -2747,6 +2827,7 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
     const int nb = min(nbmax, N - first);
     if (nb <= 0) return 0;
     RowCtx c;
+    c.meta = nullptr;
     c.scal = S.scalars + (size_t)mission * SC_N, c.mission = mission, c.lds_avail = lds_doubles - 32;
     c.d = make_dims(N, M, first, nb);
     c.w = carve(ws_base + (size_t)mission * ws_stride, c.d, nbmax);
@@ -2780,6 +2861,20 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
     PROF(8);  // batch setup: constants, SFC boxes, presolve lists, row constants
     PassIO io;
     __shared__ RowCtx c_lds;  // the sweeps' view of the row context (see sweep<>)
+#if QP_ROW_BLK > 0
+    __shared__ SweepMeta meta_lds;
+    const bool meta_ok = nb * d.M <= QP_META_G && d.ntile + 1 <= 16 && d.N <= 256 && (size_t)nb * d.M * d.N < 65536;
+    __syncthreads();
+    if (meta_ok) {
+        for (int rk = tid; rk < nb * d.M; rk += QP_THREADS) {
+            const int g = w.fperm[rk];
+            meta_lds.grp[rk] = (unsigned char)g, meta_lds.near[rk] = (unsigned char)w.fnear[g], meta_lds.all[rk] = (unsigned char)w.fcnt[g];
+            meta_lds.fbase[rk] = (unsigned short)w.fbase[g];
+        }
+        for (int t = tid; t <= d.ntile; t += QP_THREADS) meta_lds.tile_base[t] = w.tile_base[t];
+    }
+    c.meta = meta_ok ? &meta_lds : nullptr;
+#endif
     __syncthreads();
     if (tid == 0) c_lds = c;
     __syncthreads();
