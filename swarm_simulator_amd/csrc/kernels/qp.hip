@@ -1406,7 +1406,9 @@ __device__ __forceinline__ bool chol_rows(double (&a)[NK], double& dinv) {  // r
 // coefficients of row rr of the coupling block between knot j and the next knot of the chain: T_{j+dir,j}[rr][3g + q], g = rr / 3
 // (T_{j+1,j} = blockdiag(E_{knot j+1}'), T_{j-1,j} = T_{j,j-1}'; see assemble_blocks)
 __device__ __forceinline__ void coupling_coef(const QpWs& w, int j, int dir, int rr, double& e0, double& e1, double& e2) {
-    const double* E = w.Ek + 9 * (dir > 0 ? j + 1 : j);
+    // (a GLOBAL load, not a flat one: a flat load also counts on the LDS counter, and the chain's next wait for its own LDS traffic would
+    // wait for this trip to memory as well -- the very latency the early issue is meant to hide)
+    const __attribute__((address_space(1))) double* E = QGC(w.Ek) + 9 * (dir > 0 ? j + 1 : j);
     e0 = dir > 0 ? E[rr % 3] : E[3 * (rr % 3)], e1 = dir > 0 ? E[3 + rr % 3] : E[3 * (rr % 3) + 1],
     e2 = dir > 0 ? E[6 + rr % 3] : E[3 * (rr % 3) + 2];
 }
@@ -1464,16 +1466,16 @@ __device__ __forceinline__ void knot_inverse(const QpWs& w, int j, kl_lds* base,
     const double dinv = I[act ? r : 0];  // (read before the chain is told to go on: its next block overwrites I)
     kl_store_rows<NK>(m, MX, r, act);
     if (FOLLOW) kl_publish(Mdone, done_value);
-    double* Mg = w.Lf + (size_t)j * KF_STRIDE(NK);
+    __attribute__((address_space(1))) double* Mg = QG(w.Lf + (size_t)j * KF_STRIDE(NK));
     // (256-thread build: the next block's inputs, sent for a block ago by global_load_lds, are counted on this wave's memory counter; they have
     // long landed -- drain the counter HERE, so that the tiles' wait for them does not have to wait for the row stores below as well)
     if (FOLLOW && QP_FOLLOW_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (act) {  // row r of M_j and 1 / d_j -> QpWs::Lf (16 bytes per lane and store instruction: the store path of a CU is issue bound)
-        double* row = Mg + (size_t)r * NK;
+        __attribute__((address_space(1))) double* row = Mg + (size_t)r * NK;
         if ((NK & 1) == 0) {
 #pragma unroll
             for (int k = 0; k < NK; k += 2)
-                if (k + 1 >= r) *(kl_d2*)(row + k) = kl_d2{m[k], m[k + 1]};  // (M_j is upper triangular; the staging does not fetch the rest)
+                if (k + 1 >= r) *(__attribute__((address_space(1))) kl_d2*)(row + k) = kl_d2{m[k], m[k + 1]};  // (M_j is upper triangular; the staging does not fetch the rest)
         } else {
 #pragma unroll
             for (int k = 0; k < NK; ++k)
@@ -1789,8 +1791,8 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     const int nl = mid, nr = nj - 1 - mid, SF = nl > nr ? nl : nr;
     const int nsteps = 2 * SF + 1;  // SF forward steps, the middle block, SF backward steps
     lds += KS::LEAD;                                   // (zero-filled with the stage buffers below)
-    double* vec = lds + QP_STAGE_BUFS * STG;           // nj*NK: rhs -> z -> x
-    double* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KS_VLEN], then [2 chains][64] partial sums
+    kl_lds* vec = (kl_lds*)(lds + QP_STAGE_BUFS * STG);  // nj*NK: rhs -> z -> x  (LDS pointers: through generic ones every access is a flat instruction)
+    kl_lds* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KS_VLEN], then [2 chains][64] partial sums
     {  // rhs -> LDS: every thread's loads first, then its stores (one trip to memory instead of one per round; see apply_F)
         constexpr int RQ = 4;
         for (int i0 = tid; i0 < nj * NK; i0 += RQ * QP_THREADS) {
@@ -1896,7 +1898,7 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
             const bool has_prev = wave == 0 ? jb > 0 : jb + 1 < nj;
             if (has_prev) coupling_coef(w, jb - dir, dir, rr, q0, q1, q2);
         } else {
-            const double* E = w.Ek + 9 * (dir > 0 ? jb + 1 : jb);
+            const __attribute__((address_space(1))) double* E = QGC(w.Ek) + 9 * (dir > 0 ? jb + 1 : jb);
             q0 = dir > 0 ? E[3 * r3] : E[r3], q1 = dir > 0 ? E[3 * r3 + 1] : E[3 + r3], q2 = dir > 0 ? E[3 * r3 + 2] : E[6 + r3];
         }
     };
