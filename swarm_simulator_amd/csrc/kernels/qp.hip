@@ -61,7 +61,8 @@
 #define QP_BLK_PRE 1
 #endif
 #ifndef QP_BLK_MASK
-#define QP_BLK_MASK 0x10E  // the passes (bit = PASS_*) that stream in blocks: the four sweeps of the interior-point loop (BUILD, AFF, STEP, UPBUILD)
+#define QP_BLK_MASK 0x1EE  // the passes (bit = PASS_*) that stream in blocks: the four sweeps of the interior-point loop (BUILD, AFF, STEP, UPBUILD) and the polish's
+                           // (CAND, VERIFY, CAND_GEO)
 #endif
 #ifndef QP_ROW_BLK
 #define QP_ROW_BLK (QP_THREADS >= 512 ? 0 : 4)  // (round 6) frozen-row stream in BLOCKS of this many rows whose loads are issued a block ahead (see row_pass); 0 = off.
@@ -533,21 +534,21 @@ __device__ __forceinline__ void row_op(double slack, double ga, double gd, size_
     } else if (PASS == PASS_CAND) {
         const double s = PRE ? s_in : QGC(w.s)[r], z = PRE ? z_in : QGC(w.z)[r];
         wgt = (z > s || s < 1e-6) ? fmax(z / s, 1e-300) : 0.0;  // candidate for the active set; the value orders the warm start
-        w.cc[r] = wgt;
+        QG(w.cc)[r] = wgt;
         v = slack;
     } else if (PASS == PASS_CAND_GEO) {
         // candidates from the geometry alone (no interior-point iterate): rows within QP_WARM_TAU of their bound at the
         // current point.  Used from the second Gauss-Seidel pass on, where the current point is the previous pass's
         // optimum of this very batch and its active rows sit at slack ~ 0.
         wgt = slack < QP_WARM_TAU ? (slack < 1e-8 ? 1e3 : 1.0) : 0.0;
-        w.cc[r] = wgt;
+        QG(w.cc)[r] = wgt;
         v = slack;
     } else if (PASS == PASS_VERIFY) {
         const double sn = slack - gd;  // slack at x + dx
-        w.ds[r] = sn;
+        QG(w.ds)[r] = sn;
         io.vmax = fmax(io.vmax, -sn);
-        if (sn < -1e-11 && w.cc[r] == 0.0) {  // violated row that is not a candidate yet
-            w.cc[r] = 1.0;
+        if (sn < -1e-11 && QGC(w.cc)[r] == 0.0) {  // violated row that is not a candidate yet
+            QG(w.cc)[r] = 1.0;
             wgt = 1.0;
         }
     }
@@ -578,16 +579,17 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
     for (int wi = wi0; wi < wi_stop; wi += stride) {
         constexpr bool pre_b = QP_ROW_BLK > 0 && QP_BLK_PRE && ((QP_BLK_MASK >> PASS) & 1) && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
         constexpr bool all_rows = (PASS == PASS_PRESOLVE || PASS == PASS_VERIFY || PASS == PASS_CAND_GEO || PASS == PASS_CAND);
-        const __attribute__((address_space(3))) SweepMeta* mt = pre_b ? (const __attribute__((address_space(3))) SweepMeta*)c.meta : nullptr;
+        constexpr bool blk_pass = QP_ROW_BLK > 0 && ((QP_BLK_MASK >> PASS) & 1);  // passes that take the round-6 prologue (LDS look-ups, global loads, blocks)
+        const __attribute__((address_space(3))) SweepMeta* mt = blk_pass ? (const __attribute__((address_space(3))) SweepMeta*)c.meta : nullptr;
         int grp, cnt_near, cnt_all, fb;
         size_t base;
-        if (pre_b && mt) {  // (uniform) the look-ups from LDS
+        if (blk_pass && mt) {  // (uniform) the look-ups from LDS
             const int rk = wi / 6;
             grp = mt->grp[rk], cnt_near = mt->near[rk], cnt_all = mt->all[rk], fb = mt->fbase[rk];
             base = (size_t)mt->tile_base[wi >> 6] + (wi & 63);
         } else {
             grp = w.fperm[wi / 6];
-            cnt_near = w.fnear[grp], cnt_all = all_rows ? w.fcnt[grp] : cnt_near, fb = w.fbase[grp];
+            cnt_near = (all_rows && PASS != PASS_CAND) ? 0 : w.fnear[grp], cnt_all = all_rows ? w.fcnt[grp] : cnt_near, fb = w.fbase[grp];
             base = (size_t)w.tile_base[wi >> 6] + (wi & 63);
         }
         const int a = grp / M, seg = grp - a * M, i = wi % 6, j6 = 6 * seg + i, it = a * oq + j6;
@@ -597,7 +599,7 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         double xa[3], da[3], dd[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (pre_b) {
+            if (blk_pass) {
                 xa[k] = QGC(c.ctrl)[((size_t)qa * 3 + k) * oq + j6];
                 da[k] = need_da ? QGC(w.dxa)[((size_t)a * 3 + k) * oq + j6] : 0.0;
                 dd[k] = need_dd ? QGC(w.dx)[((size_t)a * 3 + k) * oq + j6] : 0.0;
@@ -637,8 +639,8 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double hi = pre_b ? QGC(w.boxhi)[((size_t)a * M + seg) * 3 + k] : w.boxhi[((size_t)a * M + seg) * 3 + k];
-            const double lo = pre_b ? QGC(w.boxlo)[((size_t)a * M + seg) * 3 + k] : w.boxlo[((size_t)a * M + seg) * 3 + k];
+            const double hi = blk_pass ? QGC(w.boxhi)[((size_t)a * M + seg) * 3 + k] : w.boxhi[((size_t)a * M + seg) * 3 + k];
+            const double lo = blk_pass ? QGC(w.boxlo)[((size_t)a * M + seg) * 3 + k] : w.boxlo[((size_t)a * M + seg) * 3 + k];
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
                 const size_t r = base + (size_t)(2 * k + side) * 64;
