@@ -576,7 +576,24 @@ __device__ void row_pass(const RowCtx& c, PassIO& io, int wi0 = threadIdx.x, int
     constexpr bool need_dd = (PASS == PASS_STEP || PASS == PASS_VERIFY || PASS == PASS_UPBUILD);
     const int ncp = nb * oq;
     const int wi_stop = wi_end < ncp ? wi_end : ncp;
-    for (int wi = wi0; wi < wi_stop; wi += stride) {
+#ifndef QP_SNAKE
+#define QP_SNAKE 0
+#endif
+    // (QP_SNAKE) tiles are ranked by falling row count and handed to the waves round robin: wave 0 gets the heaviest tile of every round.
+    // Serpentine order -- odd rounds in reverse -- evens the waves' row counts out (sums differ in the last bits: another order of addition).
+    constexpr bool snake_ok = QP_SNAKE && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
+    const bool snake = snake_ok && wi0 == (int)threadIdx.x && stride == QP_THREADS;
+    for (int rnd = 0;; ++rnd) {
+        int wi;
+        if (snake) {
+            const int wv = (int)(threadIdx.x >> 6), nw = QP_THREADS / 64;
+            if (rnd * QP_THREADS >= wi_stop) break;
+            wi = rnd * QP_THREADS + (((rnd & 1) ? nw - 1 - wv : wv) << 6) + (int)(threadIdx.x & 63);
+            if (wi >= wi_stop) continue;
+        } else {
+            wi = wi0 + rnd * stride;
+            if (wi >= wi_stop) break;
+        }
         constexpr bool pre_b = QP_ROW_BLK > 0 && QP_BLK_PRE && ((QP_BLK_MASK >> PASS) & 1) && (PASS == PASS_BUILD || PASS == PASS_AFF || PASS == PASS_STEP || PASS == PASS_UPBUILD);
         constexpr bool all_rows = (PASS == PASS_PRESOLVE || PASS == PASS_VERIFY || PASS == PASS_CAND_GEO || PASS == PASS_CAND);
         constexpr bool blk_pass = QP_ROW_BLK > 0 && ((QP_BLK_MASK >> PASS) & 1);  // passes that take the round-6 prologue (LDS look-ups, global loads, blocks)
