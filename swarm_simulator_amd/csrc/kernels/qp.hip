@@ -57,6 +57,9 @@
 #ifndef QP_ROW_PF
 #define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
 #endif
+#ifndef QP_FUSE_F
+#define QP_FUSE_F 1  // (round 6) apply_F fused into the substitutions' epilogue (see SolveOut)
+#endif
 #ifndef QP_BLK_PRE
 #define QP_BLK_PRE 1
 #endif
@@ -1802,8 +1805,15 @@ struct KsLayout {  // doubles
     static constexpr int VECS = 6 * KS_VLEN + 2 * 64;
 };
 
+// (round 6) the solution's way back to control space (apply_F) can start from the LDS vector the substitutions end with, instead of from a copy
+// in global memory written by one loop and read back by the next: dx_out != null fuses it into the epilogue (wave path only)
+struct SolveOut {
+    double* dx_out;    // [nb][3][oq] direction in control space, or null: the reduced solution goes to rhs as before
+    const double* Lk;  // QpWs::Lk
+    int oq;
+};
 template <int NK, int ROLE>
-__device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds) {
+__device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds, SolveOut so = SolveOut{nullptr, nullptr, 0}) {
     using KS = KsLayout<NK>;
     constexpr int STG = KS::STG, SCH = KS::SCH, SM = KS::SM;
     const int tid = threadIdx.x, nj = d.nj, mid = twist_mid(nj);
@@ -2064,7 +2074,27 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
         __syncthreads();
     }
     if (wave < 2) __builtin_amdgcn_s_setprio(0);
-    for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
+    if (so.dx_out) {  // apply_F from the LDS vector (same arithmetic, same order)
+        constexpr int nu = NK / 3;
+        const int oq = so.oq;
+        for (int it = tid; it < nj * nu; it += QP_THREADS) {
+            const int j = it / nu + 1, u = it % nu;
+            const kl_lds* uu = vec + (size_t)(j - 1) * NK + u * 3;
+            const __attribute__((address_space(1))) double* L = QGC(so.Lk) + 9 * j;
+            const double u0 = uu[0], u1 = uu[1], u2 = uu[2];
+            __attribute__((address_space(1))) double* o = QG(so.dx_out) + (size_t)u * oq + 6 * (j - 1) + 3;  // control points 6(j-1)+3 .. 6j+2
+            o[0] = L[0] * u0 + L[1] * u1 + L[2] * u2;
+            o[1] = L[3] * u0 + L[4] * u1 + L[5] * u2;
+            o[2] = L[6] * u0 + L[7] * u1 + L[8] * u2;
+            o[3] = u0, o[4] = u1, o[5] = u2;
+        }
+        for (int it = tid; it < nu * 6; it += QP_THREADS) {  // the pinned ends
+            const int u = it / 6, q = it % 6;
+            QG(so.dx_out)[(size_t)u * oq + (q < 3 ? q : oq - 6 + q)] = 0.0;
+        }
+    } else {
+        for (int i = tid; i < nj * NK; i += QP_THREADS) rhs[i] = vec[i];
+    }
     __threadfence_block();
     __syncthreads();
 }
@@ -2465,13 +2495,13 @@ __device__ __forceinline__ bool factor_dispatch(const QpDims& d, const QpWs& w, 
 }
 
 template <int ROLE>
-__device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA, int lds_avail) {
+__device__ __forceinline__ void solve_dispatch(const QpDims& d, const QpWs& w, double* rhs, double* lA, int lds_avail, SolveOut so = SolveOut{nullptr, nullptr, 0}) {
     if (d.nk <= 36) {
         switch (d.nk) {  // lA = start of the dynamic LDS region (the three block buffers are free between factorisations)
-            case 9: solve_staged<9, ROLE>(d, w, rhs, lA); break;
-            case 18: solve_staged<18, ROLE>(d, w, rhs, lA); break;
-            case 27: solve_staged<27, ROLE>(d, w, rhs, lA); break;
-            default: solve_staged<36, ROLE>(d, w, rhs, lA); break;
+            case 9: solve_staged<9, ROLE>(d, w, rhs, lA, so); break;
+            case 18: solve_staged<18, ROLE>(d, w, rhs, lA, so); break;
+            case 27: solve_staged<27, ROLE>(d, w, rhs, lA, so); break;
+            default: solve_staged<36, ROLE>(d, w, rhs, lA, so); break;
         }
         return;
     }
@@ -2536,24 +2566,24 @@ __device__ __forceinline__ bool factor_entry(const BlkArgs& b, const AsmArgs& A,
     if (b.nk <= 36 && wave >= 2) return factor_entry_follow(b, A, lds, flag);
     return factor_entry_chain(b, A, lds, flag);
 }
-__device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* lds) {
+__device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* lds, SolveOut so) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<0>(d, w, uni(rhs), uni(lds), uni(b.lds_avail));
+    solve_dispatch<0>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq)});
 }
-__device__ __noinline__ void solve_entry_stage(BlkArgs b, double* rhs, double* lds) {
+__device__ __noinline__ void solve_entry_stage(BlkArgs b, double* rhs, double* lds, SolveOut so) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<1>(d, w, uni(rhs), uni(lds), uni(b.lds_avail));
+    solve_dispatch<1>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq)});
 }
 // (every wave passes the same workgroup barriers in either function)
-__device__ __forceinline__ void solve_entry(const BlkArgs& b, double* rhs, double* lds) {
+__device__ __forceinline__ void solve_entry(const BlkArgs& b, double* rhs, double* lds, SolveOut so = SolveOut{nullptr, nullptr, 0}) {
     if (b.nk <= 36 && (threadIdx.x >> 6) >= 2)
-        solve_entry_stage(b, rhs, lds);
+        solve_entry_stage(b, rhs, lds, so);
     else
-        solve_entry_chain(b, rhs, lds);
+        solve_entry_chain(b, rhs, lds, so);
 }
 
 #define QP_POLISH_PART 2
@@ -3033,12 +3063,20 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
         __syncthreads();
         PROF(5);
         TRC(7, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
-        solve_entry(ba, w.rhs, lA);
-        PROF(6);
-        TRC(8, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
-        apply_F(d, w, w.rhs, w.dxa);
-        __threadfence_block();
-        __syncthreads();
+#if QP_FUSE_F && !defined(QP_TRACE)
+        if (d.nk <= 36) {
+            solve_entry(ba, w.rhs, lA, SolveOut{w.dxa, w.Lk, d.oq});  // (ends with apply_F from the LDS vector, fence and barrier)
+            PROF(6);
+        } else
+#endif
+        {
+            solve_entry(ba, w.rhs, lA);
+            PROF(6);
+            TRC(8, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
+            apply_F(d, w, w.rhs, w.dxa);
+            __threadfence_block();
+            __syncthreads();
+        }
         io.sum0 = io.sum1 = io.sum2 = 0, io.vmax = 1.0;  // vmax = max(1, max -d/x): a_aff = min(1, min -x/d)
         PROF(5);
         SWEEP(PASS_AFF);
@@ -3059,12 +3097,20 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
         __syncthreads();
         PROF(5);
         TRC(11, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
-        solve_entry(ba, w.rhs, lA);
-        PROF(6);
-        TRC(12, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
-        apply_F(d, w, w.rhs, w.dx);
-        __threadfence_block();
-        __syncthreads();
+#if QP_FUSE_F && !defined(QP_TRACE)
+        if (d.nk <= 36) {
+            solve_entry(ba, w.rhs, lA, SolveOut{w.dx, w.Lk, d.oq});
+            PROF(6);
+        } else
+#endif
+        {
+            solve_entry(ba, w.rhs, lA);
+            PROF(6);
+            TRC(12, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
+            apply_F(d, w, w.rhs, w.dx);
+            __threadfence_block();
+            __syncthreads();
+        }
         flops += 2.0 * d.nj * 4.0 * d.nk * (double)d.nk;
         io.vmax = QP_STEP_FRAC;  // alpha = min(1, frac * min -x/d) = frac / max(frac, max -d/x)
         PROF(5);
