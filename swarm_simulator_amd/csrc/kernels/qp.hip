@@ -58,7 +58,7 @@
 #define QP_ROW_PF 0  // prefetch distance (rows) of the frozen-row stream; 0 = plain loop unrolled QP_ROW_UNROLL times
 #endif
 #ifndef QP_FUSE_F
-#define QP_FUSE_F 1  // (round 6) apply_F fused into the substitutions' epilogue (see SolveOut)
+#define QP_FUSE_F 2  // (round 6) 1: apply_F fused into the substitutions' epilogue; 2: and rhs_from_acc into their prologue (see SolveOut)
 #endif
 #ifndef QP_BLK_PRE
 #define QP_BLK_PRE 1
@@ -1811,6 +1811,11 @@ struct SolveOut {
     double* dx_out;    // [nb][3][oq] direction in control space, or null: the reduced solution goes to rhs as before
     const double* Lk;  // QpWs::Lk
     int oq;
+    // ... and the right-hand side (rhs_from_acc) can be formed straight into that LDS vector: rhs_mode 1 = predictor, 2 = corrector, 0 = read rhs
+    int rhs_mode = 0;
+    const double* cpacc = nullptr;  // QpWs::cpacc
+    const double* rbase = nullptr;  // QpWs::rbase
+    double sigma_mu = 0;
 };
 template <int NK, int ROLE>
 __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, double* rhs, double* lds, SolveOut so = SolveOut{nullptr, nullptr, 0}) {
@@ -1822,7 +1827,26 @@ __device__ __forceinline__ void solve_staged(const QpDims& d, const QpWs& w, dou
     lds += KS::LEAD;                                   // (zero-filled with the stage buffers below)
     kl_lds* vec = (kl_lds*)(lds + QP_STAGE_BUFS * STG);  // nj*NK: rhs -> z -> x  (LDS pointers: through generic ones every access is a flat instruction)
     kl_lds* small = vec + ((nj * NK + 1) & ~1);        // [2 chains][A, Z, V][KS_VLEN], then [2 chains][64] partial sums
-    {  // rhs -> LDS: every thread's loads first, then its stores (one trip to memory instead of one per round; see apply_F)
+    if (so.rhs_mode) {  // rhs_from_acc into the LDS vector (same arithmetic): rhs = rbase + F'(G'v) of the sweep's accumulators
+        constexpr int nu = NK / 3;
+        const int oq = so.oq;
+        const size_t ncp = (size_t)(NK / 9) * oq;
+        const bool corrector = so.rhs_mode == 2;
+        for (int it = tid; it < nj * nu; it += QP_THREADS) {
+            const int j = it / nu + 1, u = it % nu, a = u / 3, k = u % 3;
+            double g[6];  // G'v at control points 6(j-1)+3 .. 6j+2 of (agent a, dim k)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int j6 = 6 * (j - 1) + 3 + q;
+                const __attribute__((address_space(1))) double* ac = QGC(so.cpacc) + (size_t)a * oq + j6;
+                g[q] = corrector ? ac[k * ncp] - so.sigma_mu * ac[(3 + k) * ncp] : ac[(6 + k) * ncp];
+            }
+            const __attribute__((address_space(1))) double* L = QGC(so.Lk) + 9 * j;
+            const size_t o0 = (size_t)(j - 1) * NK + u * 3;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) vec[o0 + e] = QGC(so.rbase)[o0 + e] + g[3 + e] + L[0 + e] * g[0] + L[3 + e] * g[1] + L[6 + e] * g[2];
+        }
+    } else {  // rhs -> LDS: every thread's loads first, then its stores (one trip to memory instead of one per round; see apply_F)
         constexpr int RQ = 4;
         for (int i0 = tid; i0 < nj * NK; i0 += RQ * QP_THREADS) {
             double t[RQ];
@@ -2570,13 +2594,13 @@ __device__ __noinline__ void solve_entry_chain(BlkArgs b, double* rhs, double* l
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<0>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq)});
+    solve_dispatch<0>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq), uni(so.rhs_mode), uni(so.cpacc), uni(so.rbase), so.sigma_mu});
 }
 __device__ __noinline__ void solve_entry_stage(BlkArgs b, double* rhs, double* lds, SolveOut so) {
     QpDims d;
     QpWs w;
     blk_unpack(b, d, w);
-    solve_dispatch<1>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq)});
+    solve_dispatch<1>(d, w, uni(rhs), uni(lds), uni(b.lds_avail), SolveOut{uni(so.dx_out), uni(so.Lk), uni(so.oq), uni(so.rhs_mode), uni(so.cpacc), uni(so.rbase), so.sigma_mu});
 }
 // (every wave passes the same workgroup barriers in either function)
 __device__ __forceinline__ void solve_entry(const BlkArgs& b, double* rhs, double* lds, SolveOut so = SolveOut{nullptr, nullptr, 0}) {
@@ -3058,18 +3082,25 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
         PROF(4);
         TRC(6, trc_sum(d.nk <= 36 ? w.Lf : w.Td, d.nk <= 36 ? (size_t)d.nj * 2 * d.nk * d.nk : (size_t)d.nj * d.ldb * d.ldb, red));
         // ---- predictor
-        rhs_from_acc(c, false, 0.0);  // rhs = rbase + F'G'v (v from the build sweep)
-        __threadfence_block();
-        __syncthreads();
-        PROF(5);
-        TRC(7, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
 #if QP_FUSE_F && !defined(QP_TRACE)
         if (d.nk <= 36) {
-            solve_entry(ba, w.rhs, lA, SolveOut{w.dxa, w.Lk, d.oq});  // (ends with apply_F from the LDS vector, fence and barrier)
+            if (QP_FUSE_F < 2) {
+                rhs_from_acc(c, false, 0.0);
+                __threadfence_block();
+                __syncthreads();
+            }
+            PROF(5);
+            // (QP_FUSE_F = 2: starts with rhs_from_acc into the LDS vector; ends with apply_F from it, fence and barrier)
+            solve_entry(ba, w.rhs, lA, SolveOut{w.dxa, w.Lk, d.oq, QP_FUSE_F > 1 ? 1 : 0, w.cpacc, w.rbase, 0.0});
             PROF(6);
         } else
 #endif
         {
+            rhs_from_acc(c, false, 0.0);  // rhs = rbase + F'G'v (v from the build sweep)
+            __threadfence_block();
+            __syncthreads();
+            PROF(5);
+            TRC(7, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
             solve_entry(ba, w.rhs, lA);
             PROF(6);
             TRC(8, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
@@ -3092,18 +3123,24 @@ __device__ __forceinline__ int qp_batch_body(const DevSession& S, double* ws_bas
         __threadfence_block();
         __syncthreads();
         PROF(8);
-        rhs_from_acc(c, true, io.sigma_mu);
-        __threadfence_block();
-        __syncthreads();
-        PROF(5);
-        TRC(11, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
 #if QP_FUSE_F && !defined(QP_TRACE)
         if (d.nk <= 36) {
-            solve_entry(ba, w.rhs, lA, SolveOut{w.dx, w.Lk, d.oq});
+            if (QP_FUSE_F < 2) {
+                rhs_from_acc(c, true, io.sigma_mu);
+                __threadfence_block();
+                __syncthreads();
+            }
+            PROF(5);
+            solve_entry(ba, w.rhs, lA, SolveOut{w.dx, w.Lk, d.oq, QP_FUSE_F > 1 ? 2 : 0, w.cpacc, w.rbase, io.sigma_mu});
             PROF(6);
         } else
 #endif
         {
+            rhs_from_acc(c, true, io.sigma_mu);
+            __threadfence_block();
+            __syncthreads();
+            PROF(5);
+            TRC(11, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
             solve_entry(ba, w.rhs, lA);
             PROF(6);
             TRC(12, trc_sum(w.rhs, (size_t)d.nj * d.nk, red));
